@@ -1,0 +1,46 @@
+# Builds libmcmc_hip.so (gfx950 only) in-tree, the host drivers, and the CPU
+# oracle (test infrastructure).  CMakeLists.txt builds the same targets.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC = mcmc_amd/csrc
+OBJ = build/obj
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude \
+           -DMCMC_BUILD -Wall -Wno-unused-function
+LIB = mcmc_amd/libmcmc_hip.so
+
+OBJS = $(OBJ)/chain.o $(OBJ)/chain_kind_0.o $(OBJ)/chain_kind_1.o $(OBJ)/chain_kind_2.o $(OBJ)/chain_kind_3.o \
+       $(OBJ)/xsection.o $(OBJ)/capi.o $(OBJ)/errors.o
+HDRS = $(wildcard $(CSRC)/*.hpp) include/mcmc_hip.h
+
+all: $(LIB) drivers oracle
+
+$(OBJ):
+	mkdir -p $(OBJ)
+
+$(OBJ)/chain_kind_%.o: $(CSRC)/chain_kind.hip $(HDRS) | $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DMCMC_KIND=$* -c $< -o $@
+
+$(OBJ)/%.o: $(CSRC)/%.hip $(HDRS) | $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJ)/%.o: $(CSRC)/%.cpp $(HDRS) | $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+drivers: $(LIB)
+	@if [ -f mcmc_amd/host/stepsize_main.cpp ]; then \
+	  g++ -O3 -std=c++17 -Iinclude -Imcmc_amd/host -o mcmc_amd/host/stepsize mcmc_amd/host/stepsize_main.cpp \
+	      -Lmcmc_amd -lmcmc_hip -Wl,-rpath,'$$ORIGIN/..' ; fi
+	@if [ -f mcmc_amd/host/xsection_main.cpp ]; then \
+	  g++ -O3 -std=c++17 -Iinclude -Imcmc_amd/host -o mcmc_amd/host/xsection mcmc_amd/host/xsection_main.cpp \
+	      -Lmcmc_amd -lmcmc_hip -Wl,-rpath,'$$ORIGIN/..' ; fi
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB) mcmc_amd/host/stepsize mcmc_amd/host/xsection
+	$(MAKE) -C oracle clean
+.PHONY: all drivers oracle clean

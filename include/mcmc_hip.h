@@ -1,0 +1,280 @@
+/*
+ * mcmc_hip.h -- C ABI of libmcmc_hip.so, the MI355X (gfx950) Metropolis-Hastings
+ * Monte-Carlo integration engine.
+ *
+ * The reference (ArktisDev/MCMC) has no plugin/FFI interface: its boundary is
+ * the set of kernel launches and host statistics calls made by its two
+ * drivers, stepsize/src/main.cpp and xsection/src/main.cu.
+ * Every entry point below names the reference call site it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MCMC_E* code for
+ *     argument errors, or a positive hipError_t value; mcmc_last_error()
+ *     returns a thread-local message.  The library never calls exit().
+ *   - "Layer A" (mcmc_launch_*, mcmc_chain_run, ...) takes DEVICE pointers the
+ *     caller owns plus a hipStream_t (as void*, NULL = default stream) and is
+ *     asynchronous.  It allocates nothing.
+ *   - "Layer B" (mcmc_create ... mcmc_destroy) owns its device memory and one
+ *     stream, mirrors the drivers' parameter names, and is synchronous unless
+ *     stated.  One handle is not thread-safe; distinct handles are.
+ *   - all arrays are structure-of-arrays exactly as the reference lays them
+ *     out: prevSample[nNucleons][totalThreads] (Metropolis.cuh:33,63).
+ */
+#ifndef MCMC_HIP_H
+#define MCMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCMC_OK 0
+#define MCMC_EINVAL (-1)   /* bad argument (message in mcmc_last_error) */
+#define MCMC_ENOMEM (-2)   /* workspace too small / allocation failed   */
+#define MCMC_ENODEV (-3)   /* no HIP device                              */
+
+/* Target densities: the callables of xsection/include/Distributions.cuh:7-28
+ * and stepsize/include/metropolis.hpp:9-17, selected at run time instead of
+ * as template arguments (Common.cuh:17 `typedef float (*PDF)(float)`).     */
+typedef enum {
+    MCMC_TARGET_WS = 0,      /* WoodsSaxon(r, c=p0, a=p1)     */
+    MCMC_TARGET_R2WS = 1,    /* R2WoodsSaxon(r, c=p0, a=p1)   */
+    MCMC_TARGET_GAUSS = 2,   /* Gaussian(r, variance=p0)      */
+    MCMC_TARGET_R2GAUSS = 3  /* R2Gaussian(r, variance=p0)    */
+} mcmc_target_kind;
+
+typedef struct {
+    int32_t kind; /* mcmc_target_kind */
+    float p0;
+    float p1;
+} mcmc_target;
+
+/* Accept/reject rule. */
+typedef enum {
+    MCMC_ACCEPT_RECIP = 0,        /* p' * (1/p) >= U, U in (0,1]; Metropolis.cuh:47-50 (GPU rule)       */
+    MCMC_ACCEPT_SHORTCIRCUIT = 1, /* p' > p || U < p'/p, U in [0,1); metropolis.hpp:41 (CPU rule, FP64) */
+    MCMC_ACCEPT_NODIV = 2,        /* p' >= U * p  (same rule, no reciprocal; not bit-identical at ties) */
+    MCMC_ACCEPT_LOG = 3           /* log U <= log p' - log p (log-space)                                 */
+} mcmc_accept_rule;
+
+typedef enum {
+    MCMC_MATH_PRECISE = 0, /* OCML expf/logf/..., IEEE division, no FMA contraction */
+    MCMC_MATH_FAST = 1     /* v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sin_f32 hardware ops */
+} mcmc_math_mode;
+
+#define MCMC_MAX_LAGS 49   /* stepsize/src/main.cpp:27 uses k = 1..49 */
+
+/* Length (in doubles) of the sufficient-statistics vector of one coordinate:
+ *   [0] sum y            y = x - center
+ *   [1] sum y^2
+ *   [2] accepted proposals
+ *   [3 .. 3+L)        P_k = sum_{i<n-k} y_i y_{i+k},           k = 1..L
+ *   [3+L .. 3+2L)     A_i = sum over chains of y_i,            i = 0..L-1 (first L samples of the window)
+ *   [3+2L .. 3+3L)    Z_j = sum over chains of y_{n-1-j},      j = 0..L-1 (last L samples so far)
+ * From these the host evaluates statistics.hpp:6-57 exactly (mcmc_stats_finalize). */
+#define MCMC_STATS_LEN(n_lags) (3 + 3 * (n_lags))
+
+/* ------------------------------------------------------------------ */
+/* Layer A.1 -- many-chain MH kernel with streaming statistics.
+ * Replaces MetropolisHastingsAlgorithm (stepsize/include/metropolis.hpp:28-50,
+ * called from stepsize/src/main.cpp:17) and the per-lag AutoCorrelation passes
+ * (statistics.hpp:36-57, main.cpp:27-30) for n_chains independent chains.   */
+typedef struct {
+    uint64_t n_chains;     /* chains on this device                                        */
+    uint32_t n_coords;     /* independent coordinates per chain (each its own 1-D target)  */
+    uint32_t n_lags;       /* 0..MCMC_MAX_LAGS lag products tracked per coordinate         */
+    uint64_t n_steps;      /* sweeps in this launch (`iterations`, metropolis.hpp:28)      */
+    double step_size;      /* `stepSize`, metropolis.hpp:28                                */
+    double center;         /* y = x - center is accumulated (shift-invariant statistics)   */
+    mcmc_target target;
+    int32_t precision;     /* 32 (Metropolis.cuh arithmetic) or 64 (metropolis.hpp arithmetic) */
+    int32_t accept_rule;   /* mcmc_accept_rule; 64-bit supports SHORTCIRCUIT only           */
+    int32_t math_mode;     /* mcmc_math_mode (32-bit only)                                 */
+    int32_t window_start;  /* 1: this launch starts a statistics window (ring = empty)      */
+    uint64_t seed;         /* Philox key                                                   */
+    uint64_t step_offset;  /* sweeps already done by these chains (Philox counter)         */
+    uint64_t chain_offset; /* global id of this device's chain 0 (multi-GPU partition)     */
+    void *state;           /* dev [n_coords][n_chains] float|double, in/out                */
+    double *stats;         /* dev [n_coords][MCMC_STATS_LEN(n_lags)], overwritten           */
+    void *ring;            /* dev [n_coords][n_lags][n_chains] lag history carried between launches, or NULL */
+    void *samples;         /* dev [n_steps][n_coords][n_chains] sample write-back, or NULL  */
+    const void *inj_normals;  /* dev [n_steps][n_coords][n_chains] injected N(0,1) draws, or NULL (Philox) */
+    const void *inj_uniforms; /* dev [n_steps][n_coords][n_chains] injected uniforms (rule 1 consumes them
+                                 through a per-chain cursor, like metropolis.hpp:41)         */
+    uint8_t *accept_bits;  /* dev [n_steps][n_coords][n_chains] accept flags, or NULL       */
+    void *workspace;       /* dev scratch for block partials                               */
+    size_t workspace_bytes;
+} mcmc_chain_args;
+
+/* Bytes of workspace mcmc_chain_run needs for these arguments. */
+size_t mcmc_chain_workspace_bytes(const mcmc_chain_args *a);
+
+/* Launch (asynchronous on `stream`). */
+int mcmc_chain_run(const mcmc_chain_args *a, void *stream);
+
+/* Host finalisation of a (summed) statistics vector of ONE coordinate:
+ * mean, variance (n-1; statistics.hpp:17-28), acceptance ratio
+ * (metropolis.hpp:49), rho_k for k=1..n_lags (statistics.hpp:36-45, pooled
+ * over chains; identical to the reference for n_chains == 1), and the
+ * integrated autocorrelation time 1 + 2 sum rho_k
+ * (stepsize/graphing/StepSizeAnalysis.ipynb cell 1).
+ * `stats` may be the sum over launches/devices of the [0..3+L) entries with
+ * A from the window's first launch and Z from its last.                    */
+typedef struct {
+    double mean;
+    double variance;
+    double acceptance;
+    double tau_int;
+} mcmc_chain_summary;
+
+int mcmc_stats_finalize(const double *stats, uint32_t n_lags, uint64_t n_chains, uint64_t n_steps_total,
+                        double center, mcmc_chain_summary *out, double *rho /* [n_lags] or NULL */);
+
+/* The library's random draws as device arrays [n_steps][n_chains] (any pointer
+ * may be NULL): N(0,1) proposals and accept uniforms in (0,1] of coordinate
+ * `coord` of chains chain_offset.., and the two angle uniforms of the S_AB
+ * kernel.  Replaces RandomNormal/RandomUniform (stepsize/include/random.hpp:
+ * 7-19) and curand_normal/curand_uniform (Metropolis.cuh:43,47;
+ * IntegrateSAB.cuh:51-52): Philox4x32-10 keyed by seed, counter = (chain,
+ * coord, step), so the values do not depend on launch geometry or GPU count. */
+int mcmc_launch_draws(uint64_t seed, uint64_t chain_offset, uint64_t n_chains, uint32_t coord, uint64_t step_offset,
+                      uint64_t n_steps, int math_mode, float *normals, float *uniforms, float *angle_u0,
+                      float *angle_u1, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* Layer A.2 -- xsection kernels (device pointers, reference layouts).   */
+typedef struct {
+    uint32_t nNucleonsA;        /* main.cu:43 */
+    uint32_t nNucleonsB;        /* main.cu:44 */
+    uint64_t totalThreads;      /* events on this device; main.cu:89 (`totalBlocks * threadsPerBlock`) */
+    const mcmc_target *targets; /* dev [nNucleonsA+nNucleonsB] per-nucleon density (main.cu:47-51)    */
+    float *prevSample;          /* dev [nNucleons][totalThreads]; main.cu:126                         */
+    float stepsize;             /* main.cu:149,197,335 (2.2f)                                         */
+    int32_t accept_rule;        /* MCMC_ACCEPT_RECIP or MCMC_ACCEPT_NODIV                              */
+    int32_t math_mode;
+    int32_t uniform_kind;       /* -1: kinds differ per nucleon (read from `targets` on the device);
+                                   otherwise every nucleon has this mcmc_target_kind, which selects a
+                                   kernel specialised for it (only MCMC_TARGET_R2WS is specialised)   */
+    uint64_t seed;              /* main.cu:69 */
+    uint64_t step_offset;       /* sweeps already done (replaces the curandState array, main.cu:123)  */
+    uint64_t event_offset;      /* global id of this device's event 0                                 */
+    const float *injected;      /* dev [totalThreads][draws_per_thread] injected draw streams in the
+                                   reference's consumption order, or NULL (Philox)                    */
+    uint64_t injected_stride;   /* floats per thread in `injected`                                    */
+    float sigmaNN;              /* fm^2; IntegrateSAB.cuh:11 (4.3f)                                   */
+    float beta;                 /* fm^2; IntegrateSAB.cuh:10 (0.2f)                                   */
+    void *workspace;            /* dev scratch for reductions                                         */
+    size_t workspace_bytes;
+} mcmc_xs_args;
+
+size_t mcmc_xs_workspace_bytes(const mcmc_xs_args *a);
+
+/* InitSampleArray, Metropolis.cuh:27-35 (launched at main.cu:132).  The
+ * reference's `int initSample` parameter truncates 1.0f to 1; pass the value
+ * you want stored.                                                        */
+int mcmc_launch_init_sample_array(float *prevSample, float initSample, uint32_t nNucleons, uint64_t totalThreads,
+                                  void *stream);
+
+/* WarmupMetropolis, Metropolis.cuh:83-108 (main.cu:149). */
+int mcmc_launch_warmup_metropolis(const mcmc_xs_args *a, uint32_t iterations, void *stream);
+
+/* MCIntegrate_R2, IntegrateR2.cuh:7-61 (main.cu:197,206).
+ * resultBuffer: dev [nNucleons][totalThreads] per-thread means (as the
+ * reference).  runMean: dev [nNucleons] doubles = mean over threads of each
+ * row (replaces the host Average at main.cu:221-223), or NULL.             */
+int mcmc_launch_integrate_r2(const mcmc_xs_args *a, float *resultBuffer, uint32_t samples, double *runMean,
+                             void *stream);
+
+/* MCIntegrate_S_AB, IntegrateSAB.cuh:19-97 (main.cu:335,344).
+ * resultBuffer: dev [totalThreads]; runMean: dev [1] double (main.cu:359) or NULL.
+ * hits: dev [4] doubles or NULL -- black-disk counters of the same events
+ * (visualization/GlauberVisualization.ipynb cell 2, d < 2*nucleonRadius):
+ *   [0] colliding pairs, [1] samples with >=1 collision, [2] participants,
+ *   [3] samples (totalThreads*samples).  dmax2 = (2*nucleonRadius)^2.       */
+int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuffer, uint32_t samples, float impactParameter,
+                              double *runMean, double *hits, float dmax2, void *stream);
+
+/* Mean over each row of a [rows][cols] float matrix into out[rows] doubles
+ * (device Average, Statistics.cuh:23-25; fixed-order FP64 tree).          */
+int mcmc_launch_row_mean_f32(const float *x, uint32_t rows, uint64_t cols, double *out, void *workspace,
+                             size_t workspace_bytes, void *stream);
+size_t mcmc_row_mean_workspace_bytes(uint32_t rows, uint64_t cols);
+
+/* ------------------------------------------------------------------ */
+/* Host statistics with the reference's exact arithmetic.               */
+/* Statistics.cuh:7-42,63-87 (FP32 Kahan) */
+float mcmc_Sum(const float *samples, int n);
+float mcmc_Average(const float *samples, int n);
+float mcmc_Variance(const float *samples, float avg, int n);
+float mcmc_AutoCorrelation(const float *samples, float avg, int lag, int n);
+/* statistics.hpp:6-57 (FP64 naive) */
+double mcmc_Average_f64(const double *nums, int n);
+double mcmc_Variance_f64(const double *nums, int n);
+double mcmc_AutoCorrelation_f64(const double *nums, int n, int lag);
+/* xsection/tools/XSectionAnalysis.py:3-28 -> out[6] = tot, unc, el, unc, rxn, unc (mb) */
+int mcmc_cross_sections(const double *b, const double *S_AB, const double *S_AB_stderr, int n, double *out);
+
+/* ------------------------------------------------------------------ */
+/* Layer B -- handle API with the drivers' parameter names (main.cu:38-82,
+ * same names as emitted by xsection/tools/MCMCMacro.py:305-368).          */
+typedef struct {
+    int32_t nNeutronA, nProtonA, nNeutronB, nProtonB; /* main.cu:38-41 */
+    mcmc_target neutronA, protonA, neutronB, protonB; /* per-species densities (MCMCMacro.py:159-199) */
+    int32_t totalBlocks;       /* main.cu:54 */
+    int32_t threadsPerBlock;   /* main.cu:55 */
+    int32_t samplesPerThread;  /* main.cu:56 */
+    int32_t totalRuns;         /* main.cu:58 */
+    int32_t samplesForMix;     /* main.cu:60 */
+    float b0, db;              /* main.cu:63-64 */
+    int32_t ndbs;              /* main.cu:66 */
+    uint64_t seed;             /* main.cu:69 */
+    float stepsize;            /* main.cu:149 (2.2f) */
+    float initSample;          /* main.cu:132 (1.0f) */
+    float sigmaNN, beta;       /* IntegrateSAB.cuh:10-11 */
+    int32_t accept_rule, math_mode;
+    int32_t device;            /* HIP device ordinal */
+    uint64_t event_offset;     /* global id of this device's event 0 (multi-GPU partition) */
+} mcmc_config;
+
+typedef struct mcmc_handle_s *mcmc_handle;
+
+void mcmc_config_default(mcmc_config *cfg);   /* the constants of main.cu:38-82 */
+int mcmc_create(const mcmc_config *cfg, mcmc_handle *out);   /* cudaMalloc + RandStateInit + InitSampleArray, main.cu:123-134 */
+int mcmc_destroy(mcmc_handle h);                              /* main.cu:419-422 */
+int mcmc_warmup(mcmc_handle h, float stepsize, int iterations);   /* main.cu:149-152 */
+/* One run of MCIntegrate_R2 over all threads: out_run_mean[nNucleons] (main.cu:197-223). */
+int mcmc_integrate_r2(mcmc_handle h, float stepsize, int samples, float *out_run_mean);
+/* One run of MCIntegrate_S_AB at impact parameter b (main.cu:335-359); hits may be NULL. */
+int mcmc_integrate_sab(mcmc_handle h, float stepsize, int samples, float b, float *out_run_mean, double *hits4,
+                       float dmax2);
+/* Whole RMS integration (main.cu:157-286): totalRuns runs, then per nucleon
+ * RMS and RMS_stderr (main.cu:253-258).  out arrays [nNucleons].            */
+int mcmc_run_rms(mcmc_handle h, float *rms, float *rms_stderr);
+/* Whole S_AB scan (main.cu:289-413): ndbs impact parameters; out arrays [ndbs]:
+ * b, S_AB, S_AB_stderr (main.cu:384-389); p_inel may be NULL (black-disk
+ * inelastic probability per b when dmax2 > 0).                              */
+int mcmc_run_sab_scan(mcmc_handle h, float *b, float *S_AB, float *S_AB_stderr, double *p_inel, float dmax2);
+/* Copy the chain state (prevSample, [nNucleons][totalThreads]) to the host. */
+int mcmc_get_state(mcmc_handle h, float *host_out);
+int mcmc_wait(mcmc_handle h);
+
+/* stepsize driver in one call: n_chains chains of n_steps sweeps at `step`,
+ * after n_warmup discarded sweeps; acceptance, rho_k (k=1..n_lags) and
+ * optional samples [n_steps][n_chains] (host).  precision/rule as
+ * mcmc_chain_args.  Replaces main.cpp:17-30 for many chains.               */
+int mcmc_stepsize_run(const mcmc_target *target, int precision, int accept_rule, int math_mode, double step,
+                      uint64_t n_chains, uint32_t n_coords, uint64_t n_warmup, uint64_t n_steps, uint32_t n_lags,
+                      uint64_t seed, double x0, mcmc_chain_summary *summary /* [n_coords] */,
+                      double *rho /* [n_coords][n_lags] or NULL */, void *samples_host /* or NULL */);
+
+const char *mcmc_last_error(void);
+const char *mcmc_version(void);
+int mcmc_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMC_HIP_H */

@@ -1,0 +1,482 @@
+// capi.hip -- Layer B of the C ABI: the handle API with the drivers' parameter
+// names (xsection/src/main.cu:38-82), mcmc_stepsize_run, and the host
+// statistics with the reference's arithmetic (Statistics.cuh, statistics.hpp,
+// XSectionAnalysis.py).  Built on Layer A; owns its device memory.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "host_common.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace mcmc;
+
+// ---------------------------------------------------------------------
+// Host statistics.
+// Statistics.cuh:7-20
+extern "C" float mcmc_Sum(const float *samples, int n)
+{
+    float res = 0.0f, err = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const float y = samples[i] - err;
+        const float t = res + y;
+        err = (t - res) - y;
+        res = t;
+    }
+    return res - err;
+}
+
+// Statistics.cuh:23-25
+extern "C" float mcmc_Average(const float *samples, int n) { return mcmc_Sum(samples, n) / n; }
+
+// Statistics.cuh:28-42 (population variance)
+extern "C" float mcmc_Variance(const float *samples, float avg, int n)
+{
+    float res = 0.0f, err = 0.0f;
+    for (int i = 0; i < n; i++) {
+        float y = samples[i] - avg;
+        y = y * y - err;
+        const float t = res + y;
+        err = (t - res) - y;
+        res = t;
+    }
+    return res / n;
+}
+
+// Statistics.cuh:63-87
+extern "C" float mcmc_AutoCorrelation(const float *samples, float avg, int lag, int n)
+{
+    float num = 0.0f, den = 0.0f, err = 0.0f;
+    for (int i = 0; i < n - lag; i++) {
+        const float y = (samples[i] - avg) * (samples[i + lag] - avg) - err;
+        const float t = num + y;
+        err = (t - num) - y;
+        num = t;
+    }
+    err = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const float y = (samples[i] - avg) * (samples[i] - avg) - err;
+        const float t = den + y;
+        err = (t - den) - y;
+        den = t;
+    }
+    return num / den;
+}
+
+// statistics.hpp:6-15
+extern "C" double mcmc_Average_f64(const double *nums, int n)
+{
+    double sum = 0;
+    for (int i = 0; i < n; i++) sum += nums[i];
+    return sum / n;
+}
+
+// statistics.hpp:17-34
+extern "C" double mcmc_Variance_f64(const double *nums, int n)
+{
+    const double average = mcmc_Average_f64(nums, n);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        const double temp = nums[i] - average;
+        sum += temp * temp;
+    }
+    return sum / (n - 1);
+}
+
+// statistics.hpp:36-57
+extern "C" double mcmc_AutoCorrelation_f64(const double *nums, int n, int lag)
+{
+    const double average = mcmc_Average_f64(nums, n);
+    double var = 0;
+    for (int i = 0; i < n; i++) {
+        const double temp = nums[i] - average;
+        var += temp * temp;
+    }
+    var /= (n - 1);
+    double sum = 0;
+    for (int i = 0; i < n - lag; i++) sum += (nums[i] - average) * (nums[i + lag] - average);
+    return sum / (n - lag - 1) / var;
+}
+
+// XSectionAnalysis.py:3-28
+namespace {
+double trapz(const double *x, const std::vector<double> &y, int n)
+{
+    double s = 0;
+    for (int i = 0; i + 1 < n; i++) s += (y[i] * 0.5 + y[i + 1] * 0.5) * (x[i + 1] - x[i]);
+    return s;
+}
+double trapz_unc(const double *x, const std::vector<double> &e, int n)
+{
+    double s = 0;
+    for (int i = 0; i + 1 < n; i++) {
+        const double t = std::sqrt(e[i] * e[i] * 0.5 + e[i + 1] * e[i + 1] * 0.5) * (x[i + 1] - x[i]) / 2;
+        s += t * t;
+    }
+    return std::sqrt(s);
+}
+} // namespace
+
+extern "C" int mcmc_cross_sections(const double *b, const double *S, const double *Serr, int n, double *out)
+{
+    if (!b || !S || !Serr || !out || n < 2) return set_error(MCMC_EINVAL, "mcmc_cross_sections needs n >= 2 points");
+    const double pi = 3.14159265358979323846;
+    std::vector<double> y(n), e(n);
+    for (int i = 0; i < n; i++) { y[i] = b[i] * (1 - S[i]); e[i] = b[i] * Serr[i]; }
+    out[0] = 10 * 2 * pi * 2 * trapz(b, y, n);
+    out[1] = 10 * trapz_unc(b, e, n);
+    for (int i = 0; i < n; i++) { y[i] = b[i] * (1 - S[i]) * (1 - S[i]); e[i] = b[i] * std::sqrt(2.0) * (1 - S[i]) * Serr[i]; }
+    out[2] = 10 * 2 * pi * trapz(b, y, n);
+    out[3] = 10 * trapz_unc(b, e, n);
+    for (int i = 0; i < n; i++) { y[i] = b[i] * (1 - S[i] * S[i]); e[i] = b[i] * std::sqrt(2.0) * S[i] * Serr[i]; }
+    out[4] = 10 * 2 * pi * trapz(b, y, n);
+    out[5] = 10 * trapz_unc(b, e, n);
+    return MCMC_OK;
+}
+
+// ---------------------------------------------------------------------
+// Handle.
+struct mcmc_handle_s {
+    mcmc_config cfg;
+    int nA, nB, nN;
+    uint64_t T;
+    hipStream_t stream;
+    float *d_prev;
+    mcmc_target *d_targets;
+    float *d_result;   // [nN][T]
+    double *d_means;   // [nN] + [4] hits
+    void *d_ws;
+    size_t ws_bytes;
+    uint64_t sweeps_done;
+    int uniform_kind;
+};
+
+extern "C" void mcmc_config_default(mcmc_config *c)
+{
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->nNeutronA = c->nProtonA = c->nNeutronB = c->nProtonB = 2;   // main.cu:38-41
+    const mcmc_target pdf = {MCMC_TARGET_R2WS, 2.f, 0.54f};         // main.cu:14-19
+    c->neutronA = c->protonA = c->neutronB = c->protonB = pdf;
+    c->totalBlocks = 1 << 8;        // main.cu:54
+    c->threadsPerBlock = 1 << 7;    // main.cu:55
+    c->samplesPerThread = 1 << 8;   // main.cu:56
+    c->totalRuns = 1 << 4;          // main.cu:58
+    c->samplesForMix = 1 << 13;     // main.cu:60
+    c->b0 = 0;                      // main.cu:63
+    c->db = 0.1f;                   // main.cu:64
+    c->ndbs = 200;                  // main.cu:66
+    c->seed = 314159265ull;         // MCMCMacro.py:103 (main.cu:69 seeds from the clock)
+    c->stepsize = 2.2f;             // main.cu:149
+    c->initSample = 1.0f;           // main.cu:132
+    c->sigmaNN = 4.3f;              // IntegrateSAB.cuh:11
+    c->beta = 0.2f;                 // IntegrateSAB.cuh:10
+    c->accept_rule = MCMC_ACCEPT_RECIP;
+    c->math_mode = MCMC_MATH_FAST;
+    c->device = 0;
+    c->event_offset = 0;
+}
+
+namespace {
+
+mcmc_xs_args xs_args(mcmc_handle h, float stepsize)
+{
+    mcmc_xs_args a{};
+    a.nNucleonsA = h->nA;
+    a.nNucleonsB = h->nB;
+    a.totalThreads = h->T;
+    a.targets = h->d_targets;
+    a.prevSample = h->d_prev;
+    a.stepsize = stepsize;
+    a.accept_rule = h->cfg.accept_rule;
+    a.math_mode = h->cfg.math_mode;
+    a.uniform_kind = h->uniform_kind;
+    a.seed = h->cfg.seed;
+    a.step_offset = h->sweeps_done;
+    a.event_offset = h->cfg.event_offset;
+    a.sigmaNN = h->cfg.sigmaNN;
+    a.beta = h->cfg.beta;
+    a.workspace = h->d_ws;
+    a.workspace_bytes = h->ws_bytes;
+    return a;
+}
+
+void free_handle(mcmc_handle h)
+{
+    if (!h) return;
+    if (h->d_prev) (void)hipFree(h->d_prev);
+    if (h->d_targets) (void)hipFree(h->d_targets);
+    if (h->d_result) (void)hipFree(h->d_result);
+    if (h->d_means) (void)hipFree(h->d_means);
+    if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+} // namespace
+
+extern "C" int mcmc_create(const mcmc_config *cfg, mcmc_handle *out)
+{
+    if (!cfg || !out) return set_error(MCMC_EINVAL, "null pointer");
+    if (cfg->nNeutronA < 0 || cfg->nProtonA < 0 || cfg->nNeutronB < 0 || cfg->nProtonB < 0)
+        return set_error(MCMC_EINVAL, "negative nucleon count");
+    if (cfg->totalBlocks <= 0 || cfg->threadsPerBlock <= 0) return set_error(MCMC_EINVAL, "totalBlocks and threadsPerBlock must be > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(MCMC_ENODEV, "no HIP device");
+    MCMC_HIP_CHECK(hipSetDevice(cfg->device));
+    mcmc_handle h = new mcmc_handle_s();
+    std::memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->nA = cfg->nNeutronA + cfg->nProtonA;
+    h->nB = cfg->nNeutronB + cfg->nProtonB;
+    h->nN = h->nA + h->nB;
+    h->T = (uint64_t)cfg->totalBlocks * (uint64_t)cfg->threadsPerBlock; // main.cu:89
+    if (h->nN == 0) { delete h; return set_error(MCMC_EINVAL, "no nucleons"); }
+
+    // per-nucleon densities in the order of TemplateBuilder::ConcatArray(pdfArrA, pdfArrB)
+    // (main.cu:49-51; MCMCMacro.py:315-345 concatenates protons A, neutrons A, protons B, neutrons B)
+    std::vector<mcmc_target> tg;
+    for (int i = 0; i < cfg->nProtonA; i++) tg.push_back(cfg->protonA);
+    for (int i = 0; i < cfg->nNeutronA; i++) tg.push_back(cfg->neutronA);
+    for (int i = 0; i < cfg->nProtonB; i++) tg.push_back(cfg->protonB);
+    for (int i = 0; i < cfg->nNeutronB; i++) tg.push_back(cfg->neutronB);
+    h->uniform_kind = tg[0].kind;
+    for (const auto &t : tg) {
+        if (t.kind < 0 || t.kind > 3) { delete h; return set_error(MCMC_EINVAL, "bad target kind"); }
+        if (t.kind != h->uniform_kind) h->uniform_kind = -1;
+    }
+
+#define MCMC_CREATE_CHECK(expr)                                       \
+    do {                                                              \
+        hipError_t _e = (expr);                                       \
+        if (_e != hipSuccess) {                                       \
+            free_handle(h);                                           \
+            return set_hip_error(_e, __FILE__, __LINE__);             \
+        }                                                             \
+    } while (0)
+    MCMC_CREATE_CHECK(hipStreamCreate(&h->stream));
+    MCMC_CREATE_CHECK(hipMalloc((void **)&h->d_prev, sizeof(float) * h->nN * h->T));        // main.cu:126
+    MCMC_CREATE_CHECK(hipMalloc((void **)&h->d_targets, sizeof(mcmc_target) * h->nN));
+    MCMC_CREATE_CHECK(hipMalloc((void **)&h->d_result, sizeof(float) * h->nN * h->T));      // main.cu:164
+    MCMC_CREATE_CHECK(hipMalloc((void **)&h->d_means, sizeof(double) * (h->nN + 4)));
+    mcmc_xs_args a = xs_args(h, cfg->stepsize);
+    h->ws_bytes = mcmc_xs_workspace_bytes(&a);
+    MCMC_CREATE_CHECK(hipMalloc(&h->d_ws, h->ws_bytes));
+    MCMC_CREATE_CHECK(hipMemcpy(h->d_targets, tg.data(), sizeof(mcmc_target) * h->nN, hipMemcpyHostToDevice));
+#undef MCMC_CREATE_CHECK
+    // RandStateInit (main.cu:130) has no counterpart: the Philox counter is (event, nucleon, sweep).
+    int rc = mcmc_launch_init_sample_array(h->d_prev, cfg->initSample, h->nN, h->T, h->stream); // main.cu:132
+    if (rc) { free_handle(h); return rc; }
+    hipError_t e = hipStreamSynchronize(h->stream); // main.cu:134
+    if (e != hipSuccess) { free_handle(h); return set_hip_error(e, __FILE__, __LINE__); }
+    *out = h;
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_destroy(mcmc_handle h)
+{
+    if (!h) return set_error(MCMC_EINVAL, "null handle");
+    (void)hipSetDevice(h->cfg.device);
+    free_handle(h);
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_wait(mcmc_handle h)
+{
+    if (!h) return set_error(MCMC_EINVAL, "null handle");
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_warmup(mcmc_handle h, float stepsize, int iterations)
+{
+    if (!h) return set_error(MCMC_EINVAL, "null handle");
+    if (iterations < 0) return set_error(MCMC_EINVAL, "iterations must be >= 0");
+    MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
+    mcmc_xs_args a = xs_args(h, stepsize);
+    int rc = mcmc_launch_warmup_metropolis(&a, (uint32_t)iterations, h->stream);
+    if (rc) return rc;
+    h->sweeps_done += (uint64_t)iterations;
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream)); // main.cu:151
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_integrate_r2(mcmc_handle h, float stepsize, int samples, float *out_run_mean)
+{
+    if (!h || !out_run_mean) return set_error(MCMC_EINVAL, "null pointer");
+    if (samples <= 0) return set_error(MCMC_EINVAL, "samples must be > 0");
+    MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
+    mcmc_xs_args a = xs_args(h, stepsize);
+    int rc = mcmc_launch_integrate_r2(&a, h->d_result, (uint32_t)samples, h->d_means, h->stream);
+    if (rc) return rc;
+    h->sweeps_done += (uint64_t)samples;
+    std::vector<double> m(h->nN);
+    MCMC_HIP_CHECK(hipMemcpyAsync(m.data(), h->d_means, sizeof(double) * h->nN, hipMemcpyDeviceToHost, h->stream));
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int n = 0; n < h->nN; n++) out_run_mean[n] = (float)m[n];
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_integrate_sab(mcmc_handle h, float stepsize, int samples, float b, float *out_run_mean, double *hits4,
+                                  float dmax2)
+{
+    if (!h || !out_run_mean) return set_error(MCMC_EINVAL, "null pointer");
+    if (samples <= 0) return set_error(MCMC_EINVAL, "samples must be > 0");
+    MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
+    mcmc_xs_args a = xs_args(h, stepsize);
+    int rc = mcmc_launch_integrate_sab(&a, h->d_result, (uint32_t)samples, b, h->d_means, hits4 ? h->d_means + 1 : nullptr,
+                                       dmax2, h->stream);
+    if (rc) return rc;
+    h->sweeps_done += (uint64_t)samples;
+    double m[5];
+    MCMC_HIP_CHECK(hipMemcpyAsync(m, h->d_means, sizeof(double) * (hits4 ? 5 : 1), hipMemcpyDeviceToHost, h->stream));
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    *out_run_mean = (float)m[0];
+    if (hits4) std::memcpy(hits4, m + 1, sizeof(double) * 4);
+    return MCMC_OK;
+}
+
+// main.cu:157-286
+extern "C" int mcmc_run_rms(mcmc_handle h, float *rms, float *rms_stderr)
+{
+    if (!h || !rms || !rms_stderr) return set_error(MCMC_EINVAL, "null pointer");
+    const int R = h->cfg.totalRuns;
+    if (R <= 0) return set_error(MCMC_EINVAL, "totalRuns must be > 0");
+    std::vector<float> runAverages((size_t)h->nN * R), one(h->nN);
+    for (int run = 0; run < R; run++) {
+        int rc = mcmc_integrate_r2(h, h->cfg.stepsize, h->cfg.samplesPerThread, one.data());
+        if (rc) return rc;
+        for (int n = 0; n < h->nN; n++) runAverages[(size_t)n * R + run] = one[n]; // main.cu:221-223
+    }
+    for (int n = 0; n < h->nN; n++) { // main.cu:253-258
+        const float *ra = &runAverages[(size_t)n * R];
+        const float finalR2Average = mcmc_Average(ra, R);
+        const float finalR2Stderr = std::sqrt(mcmc_Variance(ra, finalR2Average, R) / R);
+        rms[n] = std::sqrt(finalR2Average);
+        rms_stderr[n] = finalR2Stderr / (2 * rms[n]);
+    }
+    return MCMC_OK;
+}
+
+// main.cu:289-413
+extern "C" int mcmc_run_sab_scan(mcmc_handle h, float *b_out, float *S_AB, float *S_AB_stderr, double *p_inel, float dmax2)
+{
+    if (!h || !b_out || !S_AB || !S_AB_stderr) return set_error(MCMC_EINVAL, "null pointer");
+    const int R = h->cfg.totalRuns;
+    if (R <= 0) return set_error(MCMC_EINVAL, "totalRuns must be > 0");
+    std::vector<float> runAverages(R);
+    for (int dbs = 0; dbs < h->cfg.ndbs; dbs++) {
+        const float b = h->cfg.b0 + dbs * h->cfg.db; // main.cu:328
+        double inel = 0, nsamp = 0;
+        for (int run = 0; run < R; run++) {
+            double hits[4];
+            int rc = mcmc_integrate_sab(h, h->cfg.stepsize, h->cfg.samplesPerThread, b, &runAverages[run],
+                                        p_inel ? hits : nullptr, dmax2);
+            if (rc) return rc;
+            if (p_inel) { inel += hits[1]; nsamp += hits[3]; }
+        }
+        const float finalAverage = mcmc_Average(runAverages.data(), R);                  // main.cu:384
+        const float finalVariance = mcmc_Variance(runAverages.data(), finalAverage, R);  // main.cu:385
+        b_out[dbs] = b;
+        S_AB[dbs] = finalAverage;
+        S_AB_stderr[dbs] = std::sqrt(finalVariance / R);                                 // main.cu:386
+        if (p_inel) p_inel[dbs] = nsamp > 0 ? inel / nsamp : 0.0;
+    }
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_get_state(mcmc_handle h, float *host_out)
+{
+    if (!h || !host_out) return set_error(MCMC_EINVAL, "null pointer");
+    MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    MCMC_HIP_CHECK(hipMemcpy(host_out, h->d_prev, sizeof(float) * h->nN * h->T, hipMemcpyDeviceToHost));
+    return MCMC_OK;
+}
+
+// ---------------------------------------------------------------------
+// stepsize driver in one call (stepsize/src/main.cpp:17-30 for many chains).
+extern "C" int mcmc_stepsize_run(const mcmc_target *target, int precision, int accept_rule, int math_mode, double step,
+                                 uint64_t n_chains, uint32_t n_coords, uint64_t n_warmup, uint64_t n_steps, uint32_t n_lags,
+                                 uint64_t seed, double x0, mcmc_chain_summary *summary, double *rho, void *samples_host)
+{
+    if (!target || !summary) return set_error(MCMC_EINVAL, "null pointer");
+    if (n_chains == 0 || n_coords == 0 || n_steps == 0) return set_error(MCMC_EINVAL, "n_chains, n_coords and n_steps must be > 0");
+    if (precision != 32 && precision != 64) return set_error(MCMC_EINVAL, "precision must be 32 or 64");
+    const size_t esz = precision == 64 ? 8 : 4;
+    const size_t nstate = (size_t)n_chains * n_coords;
+    const int len = MCMC_STATS_LEN(n_lags);
+    void *d_state = nullptr, *d_ws = nullptr, *d_samples = nullptr;
+    double *d_stats = nullptr;
+    int rc = MCMC_OK;
+    hipError_t e = hipSuccess;
+
+    mcmc_chain_args a{};
+    a.n_chains = n_chains;
+    a.n_coords = n_coords;
+    a.n_lags = 0;
+    a.step_size = step;
+    a.center = 0.0;
+    a.target = *target;
+    a.precision = precision;
+    a.accept_rule = accept_rule;
+    a.math_mode = math_mode;
+    a.seed = seed;
+
+    std::vector<double> hstats((size_t)n_coords * len);
+    {
+        a.n_lags = n_lags;
+        const size_t ws_bytes = mcmc_chain_workspace_bytes(&a);
+        if ((e = hipMalloc(&d_state, nstate * esz)) != hipSuccess) goto hip_fail;
+        if ((e = hipMalloc(&d_ws, ws_bytes)) != hipSuccess) goto hip_fail;
+        if ((e = hipMalloc((void **)&d_stats, sizeof(double) * hstats.size())) != hipSuccess) goto hip_fail;
+        if (samples_host && (e = hipMalloc(&d_samples, (size_t)n_steps * nstate * esz)) != hipSuccess) goto hip_fail;
+        a.workspace = d_ws;
+        a.workspace_bytes = ws_bytes;
+    }
+    {
+        // x0 (metropolis.hpp:29 `double r = 1`)
+        std::vector<char> init(nstate * esz);
+        for (size_t i = 0; i < nstate; i++) {
+            if (precision == 64) ((double *)init.data())[i] = x0;
+            else ((float *)init.data())[i] = (float)x0;
+        }
+        if ((e = hipMemcpy(d_state, init.data(), init.size(), hipMemcpyHostToDevice)) != hipSuccess) goto hip_fail;
+    }
+    a.state = d_state;
+    a.stats = d_stats;
+    if (n_warmup > 0) {
+        a.n_lags = 0;
+        a.n_steps = n_warmup;
+        a.step_offset = 0;
+        a.window_start = 1;
+        if ((rc = mcmc_chain_run(&a, nullptr)) != MCMC_OK) goto done;
+    }
+    a.n_lags = n_lags;
+    a.n_steps = n_steps;
+    a.step_offset = n_warmup;
+    a.window_start = 1;
+    a.samples = d_samples;
+    // centre the accumulators on the target's bulk to limit cancellation (statistics are shift-invariant)
+    a.center = x0;
+    if ((rc = mcmc_chain_run(&a, nullptr)) != MCMC_OK) goto done;
+    if ((e = hipMemcpy(hstats.data(), d_stats, sizeof(double) * hstats.size(), hipMemcpyDeviceToHost)) != hipSuccess) goto hip_fail;
+    if (samples_host &&
+        (e = hipMemcpy(samples_host, d_samples, (size_t)n_steps * nstate * esz, hipMemcpyDeviceToHost)) != hipSuccess)
+        goto hip_fail;
+    for (uint32_t c = 0; c < n_coords; c++) {
+        rc = mcmc_stats_finalize(&hstats[(size_t)c * len], n_lags, n_chains, n_steps, a.center, &summary[c],
+                                 rho ? rho + (size_t)c * n_lags : nullptr);
+        if (rc) goto done;
+    }
+    goto done;
+hip_fail:
+    rc = set_hip_error(e, __FILE__, __LINE__);
+done:
+    if (d_state) (void)hipFree(d_state);
+    if (d_ws) (void)hipFree(d_ws);
+    if (d_stats) (void)hipFree(d_stats);
+    if (d_samples) (void)hipFree(d_samples);
+    return rc;
+}

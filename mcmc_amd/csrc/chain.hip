@@ -1,0 +1,176 @@
+// chain.hip -- host side of the many-chain MH kernel: argument checks, kernel
+// selection, launch; and the host finalisation of the statistics vector with
+// the exact formulas of stepsize/include/statistics.hpp:6-57.
+#include "chain_kernel.hpp"
+#include "host_common.hpp"
+
+using namespace mcmc;
+
+namespace mcmc {
+// one translation unit per target kind (chain_kind.hip)
+int chain_dispatch_kind_0(const mcmc_chain_args *, const ChainParams &, dim3, hipStream_t);
+int chain_dispatch_kind_1(const mcmc_chain_args *, const ChainParams &, dim3, hipStream_t);
+int chain_dispatch_kind_2(const mcmc_chain_args *, const ChainParams &, dim3, hipStream_t);
+int chain_dispatch_kind_3(const mcmc_chain_args *, const ChainParams &, dim3, hipStream_t);
+} // namespace mcmc
+
+namespace {
+
+uint32_t chain_grid_x(uint64_t n_chains)
+{
+    const uint64_t tiles = (n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK;
+    // 256 CUs x 8 resident 256-thread blocks; more tiles than that are looped
+    // over inside the kernel so that the partials buffer stays small.
+    return (uint32_t)(tiles < 2048 ? tiles : 2048);
+}
+
+} // namespace
+
+extern "C" size_t mcmc_chain_workspace_bytes(const mcmc_chain_args *a)
+{
+    if (!a) return 0;
+    return (size_t)a->n_coords * chain_grid_x(a->n_chains) * MCMC_STATS_LEN(a->n_lags) * sizeof(double);
+}
+
+extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
+{
+    if (!a) return set_error(MCMC_EINVAL, "null args");
+    if (a->n_chains == 0 || a->n_coords == 0) return set_error(MCMC_EINVAL, "n_chains and n_coords must be > 0");
+    if (a->n_coords > 65535) return set_error(MCMC_EINVAL, "n_coords must be <= 65535");
+    if (a->n_chains > (1ull << 40)) return set_error(MCMC_EINVAL, "n_chains must be <= 2^40");
+    if (a->n_lags > MCMC_MAX_LAGS) return set_error(MCMC_EINVAL, "n_lags must be <= MCMC_MAX_LAGS (49)");
+    if (!a->state || !a->stats) return set_error(MCMC_EINVAL, "state and stats must be device pointers");
+    if ((a->inj_normals == nullptr) != (a->inj_uniforms == nullptr))
+        return set_error(MCMC_EINVAL, "inj_normals and inj_uniforms must be given together");
+    if (a->n_lags > 0 && a->window_start && a->n_steps < a->n_lags)
+        return set_error(MCMC_EINVAL, "the first launch of a statistics window needs n_steps >= n_lags");
+    const size_t need = mcmc_chain_workspace_bytes(a);
+    if (!a->workspace || a->workspace_bytes < need) return set_error(MCMC_ENOMEM, "workspace smaller than mcmc_chain_workspace_bytes()");
+    if (a->target.kind < 0 || a->target.kind > 3) return set_error(MCMC_EINVAL, "bad target kind");
+
+    ChainParams p;
+    p.n_chains = a->n_chains;
+    p.n_steps = a->n_steps;
+    p.seed = a->seed;
+    p.step_offset = a->step_offset;
+    p.chain_offset = a->chain_offset;
+    p.n_coords = a->n_coords;
+    p.n_lags = a->n_lags;
+    p.n_tiles = (uint32_t)((a->n_chains + CHAIN_BLOCK - 1) / CHAIN_BLOCK);
+    p.window_start = a->window_start;
+    p.step = a->step_size;
+    p.center = a->center;
+    p.target = a->target;
+    p.state = a->state;
+    p.partials = (double *)a->workspace;
+    p.ring = a->ring;
+    p.samples = a->samples;
+    p.inj_normals = a->inj_normals;
+    p.inj_uniforms = a->inj_uniforms;
+    p.accept_bits = a->accept_bits;
+
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(chain_grid_x(a->n_chains), a->n_coords);
+    int rc;
+    switch (a->target.kind) {
+    case MCMC_TARGET_WS: rc = chain_dispatch_kind_0(a, p, grid, s); break;
+    case MCMC_TARGET_R2WS: rc = chain_dispatch_kind_1(a, p, grid, s); break;
+    case MCMC_TARGET_GAUSS: rc = chain_dispatch_kind_2(a, p, grid, s); break;
+    default: rc = chain_dispatch_kind_3(a, p, grid, s); break;
+    }
+    if (rc != MCMC_OK) return rc;
+    MCMC_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(chain_finalize_kernel, dim3(a->n_coords), dim3(256), 0, s, (const double *)a->workspace,
+                       a->stats, (int)MCMC_STATS_LEN(a->n_lags), (int)grid.x);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+// statistics.hpp:6-57 evaluated from sufficient statistics.  With y = x - center:
+//   Average      = S1/N + center                               (:6-15)
+//   Variance     = sum (y-mu)^2 / (N-1) = (S2 - N mu^2)/(N-1)  (:17-28)
+//   AutoCorr(k)  = [sum_{i<n-k} (y_i-mu)(y_{i+k}-mu) / (count_k - 1)] / Variance   (:36-45)
+// where sum (y_i-mu)(y_{i+k}-mu) = P_k - mu (F_k + B_k) + count_k mu^2,
+// F_k = S1 - sum_{j<k} Z_j (all but the last k samples), B_k = S1 - sum_{i<k} A_i.
+extern "C" int mcmc_stats_finalize(const double *stats, uint32_t n_lags, uint64_t n_chains, uint64_t n_steps_total,
+                                   double center, mcmc_chain_summary *out, double *rho)
+{
+    if (!stats || !out) return set_error(MCMC_EINVAL, "null pointer");
+    if (n_chains == 0 || n_steps_total == 0) return set_error(MCMC_EINVAL, "empty window");
+    const double N = (double)n_chains * (double)n_steps_total;
+    const double S1 = stats[0], S2 = stats[1];
+    const double mu = S1 / N;
+    out->mean = mu + center;
+    out->variance = (S2 - N * mu * mu) / (N - 1.0);
+    out->acceptance = stats[2] / N;
+    double tau = 1.0;
+    double headsum = 0.0, tailsum = 0.0;
+    for (uint32_t k = 1; k <= n_lags; ++k) {
+        headsum += stats[3 + n_lags + (k - 1)];
+        tailsum += stats[3 + 2 * n_lags + (k - 1)];
+        double r = 0.0;
+        if (n_steps_total > k) {
+            const double cnt = (double)n_chains * (double)(n_steps_total - k);
+            const double F = S1 - tailsum, B = S1 - headsum;
+            const double cov = stats[3 + (k - 1)] - mu * (F + B) + cnt * mu * mu;
+            r = cov / (cnt - 1.0) / out->variance;
+        }
+        if (rho) rho[k - 1] = r;
+        tau += 2.0 * r;
+    }
+    out->tau_int = tau;
+    return MCMC_OK;
+}
+
+// ---------------------------------------------------------------------
+// The library's draws as arrays: what RandomNormal / RandomUniform
+// (stepsize/include/random.hpp:7-19) and curand_normal / curand_uniform
+// (Metropolis.cuh:43,47; IntegrateSAB.cuh:51-52) are replaced by.
+namespace {
+template <int MATH>
+__global__ void draws_kernel(uint64_t seed, uint64_t chain_offset, uint64_t n_chains, uint32_t coord, uint64_t step_offset,
+                             uint64_t n_steps, float *normals, float *uniforms, float *u0s, float *u1s)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    const uint64_t ta = step_offset, tb = step_offset + n_steps;
+    if (n_steps == 0) return;
+    for (uint64_t blk = ta >> 1; blk <= ((tb - 1) >> 1); ++blk) {
+        const u32x4 r = draw_block(seed, chain_offset + c, coord, blk, 0u);
+        const u32x4 q = draw_block(seed, chain_offset + c, coord, blk, 1u);
+        float z0, z1;
+        box_muller<MATH>(r.x, r.y, z0, z1);
+        const uint64_t te = blk << 1;
+        if (te >= ta) {
+            const uint64_t o = (te - ta) * n_chains + c;
+            if (normals) normals[o] = z0;
+            if (uniforms) uniforms[o] = u01(r.z);
+            if (u0s) u0s[o] = u01(q.x);
+            if (u1s) u1s[o] = u01(q.y);
+        }
+        if (te + 1 < tb) {
+            const uint64_t o = (te + 1 - ta) * n_chains + c;
+            if (normals) normals[o] = z1;
+            if (uniforms) uniforms[o] = u01(r.w);
+            if (u0s) u0s[o] = u01(q.z);
+            if (u1s) u1s[o] = u01(q.w);
+        }
+    }
+}
+} // namespace
+
+extern "C" int mcmc_launch_draws(uint64_t seed, uint64_t chain_offset, uint64_t n_chains, uint32_t coord,
+                                 uint64_t step_offset, uint64_t n_steps, int math_mode, float *normals, float *uniforms,
+                                 float *angle_u0, float *angle_u1, void *stream)
+{
+    if (n_chains == 0) return set_error(MCMC_EINVAL, "n_chains must be > 0");
+    const dim3 grid((unsigned)((n_chains + 255) / 256)), block(256);
+    if (math_mode == MCMC_MATH_FAST)
+        hipLaunchKernelGGL(draws_kernel<MCMC_MATH_FAST>, grid, block, 0, (hipStream_t)stream, seed, chain_offset, n_chains,
+                           coord, step_offset, n_steps, normals, uniforms, angle_u0, angle_u1);
+    else
+        hipLaunchKernelGGL(draws_kernel<MCMC_MATH_PRECISE>, grid, block, 0, (hipStream_t)stream, seed, chain_offset,
+                           n_chains, coord, step_offset, n_steps, normals, uniforms, angle_u0, angle_u1);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}

@@ -1,0 +1,75 @@
+// chain_kind.hip -- kernel instantiations of chain_kernel.hpp for ONE target
+// kind (compiled four times with -DMCMC_KIND=0..3 so the build parallelises).
+#include "chain_kernel.hpp"
+#include "host_common.hpp"
+
+using namespace mcmc;
+
+#ifndef MCMC_KIND
+#error "compile with -DMCMC_KIND=<mcmc_target_kind>"
+#endif
+
+namespace {
+
+constexpr int NLAG_MAX = MCMC_MAX_LAGS;
+
+template <typename Real, int KIND, int RULE, int MATH>
+void pick_lag_inj(const ChainParams &p, dim3 grid, hipStream_t s, bool inj)
+{
+    if (p.n_lags == 0) {
+        if (inj) launch_chain<Real, KIND, RULE, MATH, 0, true>(p, grid, s);
+        else launch_chain<Real, KIND, RULE, MATH, 0, false>(p, grid, s);
+    } else {
+        if (inj) launch_chain<Real, KIND, RULE, MATH, NLAG_MAX, true>(p, grid, s);
+        else launch_chain<Real, KIND, RULE, MATH, NLAG_MAX, false>(p, grid, s);
+    }
+}
+
+template <typename Real, int KIND, int RULE, int MATH>
+void pick_lag(const ChainParams &p, dim3 grid, hipStream_t s)
+{
+    if (p.n_lags == 0) launch_chain<Real, KIND, RULE, MATH, 0, false>(p, grid, s);
+    else launch_chain<Real, KIND, RULE, MATH, NLAG_MAX, false>(p, grid, s);
+}
+
+template <int KIND>
+int pick_rule(const mcmc_chain_args *a, const ChainParams &p, dim3 grid, hipStream_t s)
+{
+    const bool inj = a->inj_normals != nullptr;
+    if (a->precision == 64) {
+        if (a->accept_rule != MCMC_ACCEPT_SHORTCIRCUIT)
+            return set_error(MCMC_EINVAL, "precision 64 implements accept_rule MCMC_ACCEPT_SHORTCIRCUIT only");
+        pick_lag_inj<double, KIND, MCMC_ACCEPT_SHORTCIRCUIT, MCMC_MATH_PRECISE>(p, grid, s, inj);
+        return MCMC_OK;
+    }
+    if (a->precision != 32) return set_error(MCMC_EINVAL, "precision must be 32 or 64");
+    if (a->math_mode == MCMC_MATH_PRECISE) {
+        if (a->accept_rule != MCMC_ACCEPT_RECIP)
+            return set_error(MCMC_EINVAL, "precise math implements accept_rule MCMC_ACCEPT_RECIP only (32-bit)");
+        pick_lag_inj<float, KIND, MCMC_ACCEPT_RECIP, MCMC_MATH_PRECISE>(p, grid, s, inj);
+        return MCMC_OK;
+    }
+    if (a->math_mode != MCMC_MATH_FAST) return set_error(MCMC_EINVAL, "bad math_mode");
+    switch (a->accept_rule) {
+    case MCMC_ACCEPT_RECIP: pick_lag_inj<float, KIND, MCMC_ACCEPT_RECIP, MCMC_MATH_FAST>(p, grid, s, inj); break;
+    case MCMC_ACCEPT_NODIV: pick_lag_inj<float, KIND, MCMC_ACCEPT_NODIV, MCMC_MATH_FAST>(p, grid, s, inj); break;
+    case MCMC_ACCEPT_LOG:
+        if (inj) return set_error(MCMC_EINVAL, "injected draws are not implemented for MCMC_ACCEPT_LOG");
+        pick_lag<float, KIND, MCMC_ACCEPT_LOG, MCMC_MATH_FAST>(p, grid, s);
+        break;
+    default: return set_error(MCMC_EINVAL, "32-bit accept_rule must be RECIP, NODIV or LOG");
+    }
+    return MCMC_OK;
+}
+
+} // namespace
+
+#define MCMC_CAT2(a, b) a##b
+#define MCMC_CAT(a, b) MCMC_CAT2(a, b)
+
+namespace mcmc {
+int MCMC_CAT(chain_dispatch_kind_, MCMC_KIND)(const mcmc_chain_args *a, const ChainParams &p, dim3 grid, hipStream_t s)
+{
+    return pick_rule<MCMC_KIND>(a, p, grid, s);
+}
+} // namespace mcmc

@@ -1,0 +1,297 @@
+// device_common.hpp -- Philox4x32-10 in registers, draw transforms, target
+// densities, accept rules and wave/block reductions shared by the gfx950
+// kernels.  Written for CDNA4 only (wave64, DPP row ops, v_exp/v_log/v_rcp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mcmc_hip.h"
+
+// The parity ("precise") paths must round exactly like the written
+// expressions (the oracle is built with -ffp-contract=off); fused operations
+// are requested explicitly with __builtin_fmaf where the fast paths want them.
+#pragma clang fp contract(off)
+
+namespace mcmc {
+
+// ---------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Replaces the curandStateXORWOW array
+// (xsection/include/Metropolis.cuh:10-24, 48 B/thread in HBM + curand_init
+// skip-ahead): the state is the counter, rebuilt from (chain, coord, step).
+// The key is wave-uniform, so the key schedule lives in SGPRs.
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        u32x4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// Draw convention (DESIGN.md "RNG"): ctr = (id_lo, coord<<8 | id_hi8, blk_lo,
+// tag<<24 | blk_hi24), blk = step >> 1; tag 0 = MH draws, 1 = angle draws.
+__device__ __forceinline__ u32x4 draw_block(uint64_t seed, uint64_t id, uint32_t coord, uint64_t blk, uint32_t tag)
+{
+    u32x4 c;
+    c.x = (uint32_t)id;
+    c.y = (coord << 8) | (uint32_t)((id >> 32) & 0xFFu);
+    c.z = (uint32_t)blk;
+    c.w = (tag << 24) | (uint32_t)((blk >> 32) & 0xFFFFFFu);
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// (0,1] like curand_uniform (Metropolis.cuh:47 relies on U != 0).
+__device__ __forceinline__ float u01(uint32_t r)
+{
+    return __builtin_fmaf((float)r, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+}
+
+// Box-Muller pair from two raw words.  FAST uses the hardware log2/sqrt and
+// v_sin/v_cos (argument in revolutions, so no 2*pi multiply or reduction).
+template <int MATH>
+__device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float &z_even, float &z_odd)
+{
+    const float u1 = u01(r0), u2 = u01(r1);
+    if constexpr (MATH == MCMC_MATH_FAST) {
+        // -2 ln u = -2 ln2 * log2 u
+        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+        z_even = rad * __builtin_amdgcn_cosf(u2);
+        z_odd = rad * __builtin_amdgcn_sinf(u2);
+    } else {
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float s, c;
+        sincospif(2.0f * u2, &s, &c);
+        z_even = rad * c;
+        z_odd = rad * s;
+    }
+}
+
+__device__ __forceinline__ void box_muller_f64(uint32_t r0, uint32_t r1, double &z_even, double &z_odd)
+{
+    const double u1 = ((double)r0 + 0.5) * 2.3283064365386963e-10;
+    const double u2 = ((double)r1 + 0.5) * 2.3283064365386963e-10;
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    z_even = rad * c;
+    z_odd = rad * s;
+}
+
+// ---------------------------------------------------------------------
+// Target densities (Distributions.cuh:7-28, metropolis.hpp:9-17) with the
+// parameters pre-digested once per launch.
+template <typename Real>
+struct Target {
+    int kind;
+    Real p0, p1; // WS: c, a.  Gauss: variance
+    // fast-path constants (float only)
+    float k1, k0; // WS: exp2(k1*r + k0) == exp((r-c)/a); Gauss: exp2(k1*r*r)
+};
+
+template <typename Real>
+__device__ __forceinline__ Target<Real> make_target(const mcmc_target &t)
+{
+    Target<Real> o;
+    o.kind = t.kind;
+    o.p0 = (Real)t.p0;
+    o.p1 = (Real)t.p1;
+    const float log2e = 1.4426950408889634f;
+    if (t.kind == MCMC_TARGET_WS || t.kind == MCMC_TARGET_R2WS) {
+        o.k1 = log2e / t.p1;
+        o.k0 = -t.p0 * log2e / t.p1;
+    } else {
+        o.k1 = -log2e / (2.0f * t.p0);
+        o.k0 = 0.0f;
+    }
+    return o;
+}
+
+// Precise form: the written expression of the reference, KIND is a template
+// argument so the switch costs nothing in the loop.
+template <int KIND>
+__device__ __forceinline__ float pdf_precise(const Target<float> &t, float r)
+{
+    if (r < 0.0f) return 0.0f;
+    if constexpr (KIND == MCMC_TARGET_WS) return 1 / (1 + expf((r - t.p0) / t.p1));
+    if constexpr (KIND == MCMC_TARGET_R2WS) return r * r / (1 + expf((r - t.p0) / t.p1));
+    if constexpr (KIND == MCMC_TARGET_GAUSS) return expf(-r * r / (2 * t.p0));
+    return r * r * expf(-r * r / (2 * t.p0));
+}
+
+template <int KIND>
+__device__ __forceinline__ double pdf_precise(const Target<double> &t, double r)
+{
+    if (r < 0.0) return 0.0;
+    if constexpr (KIND == MCMC_TARGET_WS) return 1 / (1 + exp((r - t.p0) / t.p1));
+    if constexpr (KIND == MCMC_TARGET_R2WS) return r * r / (1 + exp((r - t.p0) / t.p1));
+    if constexpr (KIND == MCMC_TARGET_GAUSS) return exp(-r * r / (2 * t.p0));
+    return r * r * exp(-r * r / (2 * t.p0));
+}
+
+// Fast form: one FMA feeds v_exp_f32 (2^x), v_rcp_f32 for the quotient.
+template <int KIND>
+__device__ __forceinline__ float pdf_fast(const Target<float> &t, float r)
+{
+    float p;
+    if constexpr (KIND == MCMC_TARGET_WS) {
+        p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(r, t.k1, t.k0)));
+    } else if constexpr (KIND == MCMC_TARGET_R2WS) {
+        p = (r * r) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(r, t.k1, t.k0)));
+    } else if constexpr (KIND == MCMC_TARGET_GAUSS) {
+        p = __builtin_amdgcn_exp2f(r * r * t.k1);
+    } else {
+        const float r2 = r * r;
+        p = r2 * __builtin_amdgcn_exp2f(r2 * t.k1);
+    }
+    return r < 0.0f ? 0.0f : p;
+}
+
+// log density (natural log) for the log-space rule; -inf for r < 0 (and r == 0 for r^2 targets).
+template <int KIND>
+__device__ __forceinline__ float logpdf_fast(const Target<float> &t, float r)
+{
+    const float ln2 = 0.6931471805599453f;
+    float lp;
+    if constexpr (KIND == MCMC_TARGET_WS || KIND == MCMC_TARGET_R2WS) {
+        // -ln(1 + e^z) = -ln2 * log2(1 + 2^(z log2e))
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(r, t.k1, t.k0));
+        lp = -__builtin_amdgcn_logf(1.0f + e);
+        if constexpr (KIND == MCMC_TARGET_R2WS) lp = __builtin_fmaf(2.0f, __builtin_amdgcn_logf(r), lp);
+        lp *= ln2;
+    } else {
+        lp = r * r * t.k1 * ln2; // -r^2/(2v)
+        if constexpr (KIND == MCMC_TARGET_R2GAUSS) lp = __builtin_fmaf(2.0f * ln2, __builtin_amdgcn_logf(r), lp);
+    }
+    return r < 0.0f ? -__builtin_inff() : lp;
+}
+
+template <int KIND, int MATH>
+__device__ __forceinline__ float pdf_eval(const Target<float> &t, float r)
+{
+    if constexpr (MATH == MCMC_MATH_FAST) return pdf_fast<KIND>(t, r);
+    else return pdf_precise<KIND>(t, r);
+}
+
+// ---------------------------------------------------------------------
+// One MH proposal in FP32 (a5, Metropolis.cuh:40-52).  `aux` is the cached
+// per-chain quantity of the rule: 1/p (RECIP), p (NODIV) or log p (LOG).
+template <int KIND, int RULE, int MATH>
+__device__ __forceinline__ float mh_aux_init(const Target<float> &t, float x)
+{
+    if constexpr (RULE == MCMC_ACCEPT_RECIP) {
+        const float p = pdf_eval<KIND, MATH>(t, x);
+        if constexpr (MATH == MCMC_MATH_FAST) return __builtin_amdgcn_rcpf(p);
+        else return 1.f / p; // Metropolis.cuh:64
+    } else if constexpr (RULE == MCMC_ACCEPT_NODIV) {
+        return pdf_eval<KIND, MATH>(t, x);
+    } else {
+        return logpdf_fast<KIND>(t, x);
+    }
+}
+
+template <int KIND, int RULE, int MATH>
+__device__ __forceinline__ bool mh_step(const Target<float> &t, float &x, float &aux, float step, float normal,
+                                        float uniform)
+{
+    float next;
+    if constexpr (MATH == MCMC_MATH_FAST) next = __builtin_fmaf(step, normal, x);
+    else next = x + step * normal; // Metropolis.cuh:43
+    bool take;
+    if constexpr (RULE == MCMC_ACCEPT_RECIP) {
+        const float pn = pdf_eval<KIND, MATH>(t, next);
+        take = pn * aux >= uniform; // Metropolis.cuh:47
+        float inv;
+        if constexpr (MATH == MCMC_MATH_FAST) inv = __builtin_amdgcn_rcpf(pn);
+        else inv = 1 / pn; // Metropolis.cuh:50
+        aux = take ? inv : aux;
+    } else if constexpr (RULE == MCMC_ACCEPT_NODIV) {
+        const float pn = pdf_eval<KIND, MATH>(t, next);
+        take = pn >= uniform * aux;
+        // p' == 0 with p == 0 can only happen for a bad start; never move onto p' == 0
+        take = take && (pn > 0.0f);
+        aux = take ? pn : aux;
+    } else {
+        const float lpn = logpdf_fast<KIND>(t, next);
+        const float lu = 0.6931471805599453f * __builtin_amdgcn_logf(uniform);
+        take = lu <= lpn - aux;
+        aux = take ? lpn : aux;
+    }
+    x = take ? next : x;
+    return take;
+}
+
+// ---------------------------------------------------------------------
+// Wavefront (64 lanes) reductions with DPP row operations, then the two
+// cross-row steps through the permute network; block reductions through LDS.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    const long long r = ((long long)hi << 32) | (long long)(unsigned int)lo;
+    return __builtin_bit_cast(double, r);
+}
+
+constexpr int DPP_QUAD_XOR1 = 0xB1;    // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;    // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// Sum over all 64 lanes; every lane receives the total.
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Product over the G lanes of an aligned group (G power of two <= 64).
+template <int G>
+__device__ __forceinline__ float group_prod(float v)
+{
+    if constexpr (G >= 2) v *= dpp_f32<DPP_QUAD_XOR1>(v);
+    if constexpr (G >= 4) v *= dpp_f32<DPP_QUAD_XOR2>(v);
+    if constexpr (G >= 8) v *= dpp_f32<DPP_ROW_HALF_MIRROR>(v);
+    if constexpr (G >= 16) v *= dpp_f32<DPP_ROW_MIRROR>(v);
+    if constexpr (G >= 32) v *= __shfl_xor(v, 16, 64);
+    if constexpr (G >= 64) v *= __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ uint32_t group_sum_u32(uint32_t v)
+{
+    if constexpr (G >= 2) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_XOR1, 0xF, 0xF, true);
+    if constexpr (G >= 4) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_XOR2, 0xF, 0xF, true);
+    if constexpr (G >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_HALF_MIRROR, 0xF, 0xF, true);
+    if constexpr (G >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_MIRROR, 0xF, 0xF, true);
+    if constexpr (G >= 32) v += (uint32_t)__shfl_xor((int)v, 16, 64);
+    if constexpr (G >= 64) v += (uint32_t)__shfl_xor((int)v, 32, 64);
+    return v;
+}
+
+} // namespace mcmc

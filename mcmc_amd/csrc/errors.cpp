@@ -1,0 +1,34 @@
+// errors.cpp -- thread-local last-error string of the C ABI.
+#include <cstdio>
+#include <cstring>
+
+#include "host_common.hpp"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+namespace mcmc {
+
+int set_error(int code, const char *msg)
+{
+    std::snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int set_hip_error(hipError_t e, const char *file, int line)
+{
+    std::snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+    return (int)e;
+}
+
+} // namespace mcmc
+
+extern "C" const char *mcmc_last_error(void) { return g_err; }
+extern "C" const char *mcmc_version(void) { return "mcmc_hip 0.1 (gfx950)"; }
+extern "C" int mcmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}

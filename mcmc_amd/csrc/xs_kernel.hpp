@@ -1,0 +1,437 @@
+// xs_kernel.hpp -- the xsection device path:
+//   xs_chain_kernel : WarmupMetropolis (Metropolis.cuh:83-108) and
+//                     MCIntegrate_R2 (IntegrateR2.cuh:7-61).  The Gibbs sweep of
+//                     the reference is nN independent 1-D chains (Metropolis.cuh:
+//                     75-79 shares only the RNG stream), so with a counter RNG
+//                     every (event, nucleon) pair is its own lane.
+//   sab_kernel      : MCIntegrate_S_AB (IntegrateSAB.cuh:19-97).  One event per
+//                     group of G lanes; nucleon state and transverse positions
+//                     live in LDS, the A x B product is tiled: each lane keeps
+//                     up to JB nucleons of B in registers and sweeps the A
+//                     positions broadcast from LDS.
+//   row reductions  : device Average (Statistics.cuh:23-25) in FP64, fixed order.
+#pragma once
+#include "device_common.hpp"
+
+namespace mcmc {
+
+constexpr int XS_BLOCK = 256;
+
+struct XsParams {
+    uint64_t T;            // events on this device (reference totalThreads)
+    uint64_t seed, step_offset, event_offset;
+    uint64_t inj_stride;
+    uint32_t nA, nB;
+    uint32_t samples;
+    float stepsize;
+    float b;               // impact parameter
+    float G0;              // sigmaNN / (4 PI beta), reference float arithmetic
+    float twoBeta;         // 2.f * beta
+    float negk2;           // -log2(e) / (2 beta)
+    float dmax2;
+    int do_hits;
+    const mcmc_target *targets;
+    float *prevSample;
+    const float *injected;
+    float *result;         // R2: [nN][T]; SAB: [T]; warm-up: unused
+    uint32_t *hits;        // SAB: [3][T] per-event counters, or nullptr
+};
+
+__global__ void init_sample_kernel(float *prevSample, float v, uint64_t total)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) prevSample[i] = v;
+}
+
+// ---------------------------------------------------------------------
+// grid = (ceil(T/256), nN): blockIdx.y is the nucleon, so the target kind is
+// block-uniform and selected once outside the sweep loop.
+template <int KIND, int RULE, int MATH, bool INJ, bool R2>
+__device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_target &mt, uint32_t n, uint64_t e, bool valid)
+{
+    const Target<float> tg = make_target<float>(mt);
+    const uint32_t nN = p.nA + p.nB;
+    const uint64_t idx = (uint64_t)n * p.T + e;
+    float x = p.prevSample[idx];
+    float aux = mh_aux_init<KIND, RULE, MATH>(tg, x);
+    float sum = 0.0f, err = 0.0f;
+    const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
+    const uint64_t gid = p.event_offset + e;
+
+    auto one = [&](uint64_t t, float z, float u) {
+        if constexpr (INJ) {
+            const float *d = p.injected + e * p.inj_stride + ((t - ta) * nN + n) * 2;
+            z = d[0];
+            u = d[1];
+        }
+        mh_step<KIND, RULE, MATH>(tg, x, aux, p.stepsize, z, u);
+        if constexpr (R2) { // IntegrateR2.cuh:38-46
+            float y = x * x;
+            y -= err;
+            const float tt = sum + y;
+            err = (tt - sum) - y;
+            sum = tt;
+        }
+    };
+
+    if (p.samples > 0) {
+        for (uint64_t blk = ta >> 1; blk <= ((tb - 1) >> 1); ++blk) {
+            float z0 = 0, z1 = 0, u0 = 0, u1 = 0;
+            if constexpr (!INJ) {
+                const u32x4 r = draw_block(p.seed, gid, n, blk, 0u);
+                box_muller<MATH>(r.x, r.y, z0, z1);
+                u0 = u01(r.z);
+                u1 = u01(r.w);
+            }
+            const uint64_t te = blk << 1;
+            if (te >= ta) one(te, z0, u0);
+            if (te + 1 < tb) one(te + 1, z1, u1);
+        }
+    }
+    if (valid) {
+        p.prevSample[idx] = x;
+        if constexpr (R2) p.result[idx] = (sum - err) / p.samples; // IntegrateR2.cuh:51
+    }
+}
+
+template <int RULE, int MATH, bool INJ, bool R2>
+__global__ __launch_bounds__(XS_BLOCK) void xs_chain_kernel(const XsParams p)
+{
+    const uint32_t n = blockIdx.y;
+    const uint64_t e0 = (uint64_t)blockIdx.x * XS_BLOCK + threadIdx.x;
+    const bool valid = e0 < p.T;
+    const uint64_t e = valid ? e0 : 0;
+    const mcmc_target mt = p.targets[n];
+    switch (mt.kind) {
+    case MCMC_TARGET_WS: xs_chain_body<MCMC_TARGET_WS, RULE, MATH, INJ, R2>(p, mt, n, e, valid); break;
+    case MCMC_TARGET_R2WS: xs_chain_body<MCMC_TARGET_R2WS, RULE, MATH, INJ, R2>(p, mt, n, e, valid); break;
+    case MCMC_TARGET_GAUSS: xs_chain_body<MCMC_TARGET_GAUSS, RULE, MATH, INJ, R2>(p, mt, n, e, valid); break;
+    default: xs_chain_body<MCMC_TARGET_R2GAUSS, RULE, MATH, INJ, R2>(p, mt, n, e, valid); break;
+    }
+}
+
+// ---------------------------------------------------------------------
+// Glauber S_AB kernel.
+struct TgtLds {
+    float p0, p1, k1, k0;
+    int kind;
+};
+
+template <int KIND /* -1: per-nucleon kind */, int RULE, int MATH>
+__device__ __forceinline__ void sab_mh(const TgtLds &tl, float &x, float &aux, float step, float z, float u)
+{
+    Target<float> tg;
+    tg.kind = tl.kind;
+    tg.p0 = tl.p0;
+    tg.p1 = tl.p1;
+    tg.k1 = tl.k1;
+    tg.k0 = tl.k0;
+    if constexpr (KIND >= 0) {
+        mh_step<KIND, RULE, MATH>(tg, x, aux, step, z, u);
+    } else {
+        switch (tl.kind) {
+        case MCMC_TARGET_WS: mh_step<MCMC_TARGET_WS, RULE, MATH>(tg, x, aux, step, z, u); break;
+        case MCMC_TARGET_R2WS: mh_step<MCMC_TARGET_R2WS, RULE, MATH>(tg, x, aux, step, z, u); break;
+        case MCMC_TARGET_GAUSS: mh_step<MCMC_TARGET_GAUSS, RULE, MATH>(tg, x, aux, step, z, u); break;
+        default: mh_step<MCMC_TARGET_R2GAUSS, RULE, MATH>(tg, x, aux, step, z, u); break;
+        }
+    }
+}
+
+template <int KIND, int RULE, int MATH>
+__device__ __forceinline__ float sab_aux_init(const TgtLds &tl, float x)
+{
+    Target<float> tg;
+    tg.kind = tl.kind;
+    tg.p0 = tl.p0;
+    tg.p1 = tl.p1;
+    tg.k1 = tl.k1;
+    tg.k0 = tl.k0;
+    if constexpr (KIND >= 0) {
+        return mh_aux_init<KIND, RULE, MATH>(tg, x);
+    } else {
+        switch (tl.kind) {
+        case MCMC_TARGET_WS: return mh_aux_init<MCMC_TARGET_WS, RULE, MATH>(tg, x);
+        case MCMC_TARGET_R2WS: return mh_aux_init<MCMC_TARGET_R2WS, RULE, MATH>(tg, x);
+        case MCMC_TARGET_GAUSS: return mh_aux_init<MCMC_TARGET_GAUSS, RULE, MATH>(tg, x);
+        default: return mh_aux_init<MCMC_TARGET_R2GAUSS, RULE, MATH>(tg, x);
+        }
+    }
+}
+
+// Transverse position of a nucleon at radius r from two uniforms
+// (IntegrateSAB.cuh:50-61,70-73): isotropic direction, z dropped.
+template <int MATH>
+__device__ __forceinline__ float2 transverse(float r, float u0, float u1)
+{
+    float ct = 1 - 2 * u0;
+    float2 o;
+    if constexpr (MATH == MCMC_MATH_FAST) {
+        const float st = __builtin_amdgcn_sqrtf(__builtin_fmaf(-ct, ct, 1.0f));
+        const float rs = r * st;
+        o.x = rs * __builtin_amdgcn_cosf(u1); // cos(2 pi u1): v_cos takes revolutions
+        o.y = rs * __builtin_amdgcn_sinf(u1);
+    } else {
+        const float st = sqrtf(1 - ct * ct);
+        const float ph = 2 * u1;
+        o.x = r * st * cospif(ph);
+        o.y = r * st * sinpif(ph);
+    }
+    return o;
+}
+
+// One A x B sweep for this lane's B nucleons j = j0 + lg + q*G, q < JB.
+template <int G, int JB, int MATH>
+__device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, uint32_t j0, int lg, float &prod,
+                                          uint32_t &ncoll, uint32_t &npartA_marks, uint32_t &partB, uint32_t *partA_lds,
+                                          int e_local)
+{
+    float bx[JB], by[JB], pr[JB];
+    uint32_t hb[JB];
+#pragma unroll
+    for (int q = 0; q < JB; ++q) {
+        const uint32_t j = j0 + lg + q * G;
+        const bool ok = j < p.nB;
+        const float2 v = trE[p.nA + (ok ? j : 0)];
+        bx[q] = ok ? v.x : 1.0e30f; // d^2 = inf -> Gamma = 0 -> factor exactly 1, never a hit
+        by[q] = ok ? v.y : 0.0f;
+        pr[q] = 1.0f;
+        hb[q] = 0;
+    }
+    for (uint32_t i = 0; i < p.nA; ++i) {
+        const float2 a = trE[i]; // same address for the whole group: LDS broadcast
+        uint32_t hit_i = 0;
+#pragma unroll
+        for (int q = 0; q < JB; ++q) {
+            const float dx = a.x - bx[q]; // a.x already holds impactParameter + ux (IntegrateSAB.cuh:75)
+            const float dy = a.y - by[q];
+            float f, d2;
+            if constexpr (MATH == MCMC_MATH_FAST) {
+                d2 = __builtin_fmaf(dy, dy, dx * dx);
+                f = __builtin_fmaf(-p.G0, __builtin_amdgcn_exp2f(d2 * p.negk2), 1.0f);
+            } else {
+                d2 = dx * dx + dy * dy;
+                f = 1 - p.G0 * expf(-d2 / p.twoBeta); // IntegrateSAB.cuh:12,75
+            }
+            pr[q] *= f;
+            if (p.do_hits) {
+                const uint32_t h = d2 < p.dmax2 ? 1u : 0u;
+                ncoll += h;
+                hb[q] |= h;
+                hit_i |= h;
+            }
+        }
+        if (p.do_hits && hit_i) partA_lds[e_local * p.nA + i] = 1u; // benign race: every writer stores 1
+    }
+#pragma unroll
+    for (int q = 0; q < JB; ++q) {
+        prod *= pr[q];
+        partB += hb[q];
+    }
+    (void)npartA_marks;
+}
+
+template <int G, int KIND, int RULE, int MATH, bool INJ>
+__global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
+{
+    constexpr int EPB = XS_BLOCK / G; // events per block
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t nN = p.nA + p.nB;
+    // LDS carve-up (all in one array):
+    //   TgtLds  tgt[nN]
+    //   float2  st [EPB][nN]   (x, aux)
+    //   float2  trA[EPB][nN]   transverse positions, even sweep of the pair
+    //   float2  trB[EPB][nN]   odd sweep
+    //   uint32  partA[EPB][nA] participant marks (hits only)
+    TgtLds *tgt = reinterpret_cast<TgtLds *>(smem);
+    size_t off = ((sizeof(TgtLds) * nN + 15) / 16) * 16;
+    float2 *st = reinterpret_cast<float2 *>(smem + off);
+    off += sizeof(float2) * (size_t)EPB * nN;
+    float2 *trA = reinterpret_cast<float2 *>(smem + off);
+    off += sizeof(float2) * (size_t)EPB * nN;
+    float2 *trB = reinterpret_cast<float2 *>(smem + off);
+    off += sizeof(float2) * (size_t)EPB * nN;
+    uint32_t *partA = reinterpret_cast<uint32_t *>(smem + off);
+
+    const int tid = threadIdx.x;
+    const int e_local = tid / G;
+    const int lg = tid % G;
+    const uint64_t e0 = (uint64_t)blockIdx.x * EPB + e_local;
+    const bool valid = e0 < p.T;
+    const uint64_t e = valid ? e0 : 0;
+    const uint64_t gid = p.event_offset + e;
+
+    for (uint32_t n = tid; n < nN; n += XS_BLOCK) {
+        const mcmc_target mt = p.targets[n];
+        const Target<float> t = make_target<float>(mt);
+        TgtLds tl;
+        tl.p0 = t.p0;
+        tl.p1 = t.p1;
+        tl.k1 = t.k1;
+        tl.k0 = t.k0;
+        tl.kind = t.kind;
+        tgt[n] = tl;
+    }
+    __syncthreads();
+    float2 *stE = st + (size_t)e_local * nN;
+    float2 *trAE = trA + (size_t)e_local * nN;
+    float2 *trBE = trB + (size_t)e_local * nN;
+    for (uint32_t n = lg; n < nN; n += G) { // CopyLocalMHVars, Metropolis.cuh:61-66
+        const float x = p.prevSample[(uint64_t)n * p.T + e];
+        stE[n] = make_float2(x, sab_aux_init<KIND, RULE, MATH>(tgt[n], x));
+    }
+
+    float sum = 0.0f, err = 0.0f;
+    uint32_t h_coll = 0, h_inel = 0, h_part = 0;
+    const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
+
+    auto pair_sweep = [&](const float2 *trE) {
+        float prod = 1.0f;
+        uint32_t ncoll = 0, partB = 0, dummy = 0;
+        for (uint32_t j0 = 0; j0 < p.nB;) {
+            const uint32_t rem = p.nB - j0;
+            if (rem > 2 * G) {
+                sab_pairs<G, 4, MATH>(p, trE, j0, lg, prod, ncoll, dummy, partB, partA, e_local);
+                j0 += 4 * G;
+            } else if (rem > G) {
+                sab_pairs<G, 2, MATH>(p, trE, j0, lg, prod, ncoll, dummy, partB, partA, e_local);
+                j0 += 2 * G;
+            } else {
+                sab_pairs<G, 1, MATH>(p, trE, j0, lg, prod, ncoll, dummy, partB, partA, e_local);
+                j0 += G;
+            }
+        }
+        float y = group_prod<G>(prod);
+        // Kahan, IntegrateSAB.cuh:81-85 (every lane of the group carries the same sum)
+        y -= err;
+        const float tt = sum + y;
+        err = (tt - sum) - y;
+        sum = tt;
+        if (p.do_hits) {
+            ncoll = group_sum_u32<G>(ncoll);
+            partB = group_sum_u32<G>(partB);
+            h_coll += ncoll;
+            h_inel += ncoll > 0 ? 1u : 0u;
+            h_part += partB;
+        }
+    };
+
+    if (p.samples > 0) {
+        for (uint64_t blk = ta >> 1; blk <= ((tb - 1) >> 1); ++blk) {
+            const uint64_t te = blk << 1;
+            const bool actA = te >= ta, actB = te + 1 < tb;
+            for (uint32_t n = lg; n < nN; n += G) {
+                float2 s = stE[n];
+                const TgtLds tl = tgt[n];
+                float z0 = 0, z1 = 0, u0 = 0, u1 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                if constexpr (!INJ) {
+                    const u32x4 r = draw_block(p.seed, gid, n, blk, 0u);
+                    box_muller<MATH>(r.x, r.y, z0, z1);
+                    u0 = u01(r.z);
+                    u1 = u01(r.w);
+                    const u32x4 q = draw_block(p.seed, gid, n, blk, 1u);
+                    a0 = u01(q.x);
+                    a1 = u01(q.y);
+                    a2 = u01(q.z);
+                    a3 = u01(q.w);
+                }
+                const float shift = n < p.nA ? p.b : 0.0f;
+                if (actA) {
+                    if constexpr (INJ) {
+                        const float *d = p.injected + e * p.inj_stride + (te - ta) * nN * 4;
+                        z0 = d[2 * n];
+                        u0 = d[2 * n + 1];
+                        a0 = d[2 * nN + 2 * n];
+                        a1 = d[2 * nN + 2 * n + 1];
+                    }
+                    sab_mh<KIND, RULE, MATH>(tl, s.x, s.y, p.stepsize, z0, u0);
+                    float2 t = transverse<MATH>(s.x, a0, a1);
+                    if (n < p.nA) t.x = shift + t.x;
+                    trAE[n] = t;
+                }
+                if (actB) {
+                    if constexpr (INJ) {
+                        const float *d = p.injected + e * p.inj_stride + (te + 1 - ta) * nN * 4;
+                        z1 = d[2 * n];
+                        u1 = d[2 * n + 1];
+                        a2 = d[2 * nN + 2 * n];
+                        a3 = d[2 * nN + 2 * n + 1];
+                    }
+                    sab_mh<KIND, RULE, MATH>(tl, s.x, s.y, p.stepsize, z1, u1);
+                    float2 t = transverse<MATH>(s.x, a2, a3);
+                    if (n < p.nA) t.x = shift + t.x;
+                    trBE[n] = t;
+                }
+                stE[n] = s;
+            }
+            if (p.do_hits)
+                for (uint32_t i = lg; i < p.nA; i += G) partA[e_local * p.nA + i] = 0u;
+            __syncthreads();
+            if (actA) pair_sweep(trAE);
+            if (p.do_hits) {
+                __syncthreads();
+                uint32_t c = 0;
+                for (uint32_t i = lg; i < p.nA; i += G) {
+                    c += partA[e_local * p.nA + i];
+                    partA[e_local * p.nA + i] = 0u;
+                }
+                if (actA) h_part += group_sum_u32<G>(c);
+                __syncthreads();
+            }
+            if (actB) pair_sweep(trBE);
+            if (p.do_hits) {
+                __syncthreads();
+                uint32_t c = 0;
+                for (uint32_t i = lg; i < p.nA; i += G) c += partA[e_local * p.nA + i];
+                if (actB) h_part += group_sum_u32<G>(c);
+            }
+            __syncthreads();
+        }
+    }
+
+    for (uint32_t n = lg; n < nN; n += G)
+        if (valid) p.prevSample[(uint64_t)n * p.T + e] = stE[n].x;
+    if (valid && lg == 0) {
+        p.result[e] = (sum - err) / p.samples; // IntegrateSAB.cuh:88
+        if (p.hits != nullptr) {
+            p.hits[e] = h_coll;
+            p.hits[p.T + e] = h_inel;
+            p.hits[2 * p.T + e] = h_part;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------
+// Row reductions: out[row] = scale * sum(x[row][:]) in FP64, two fixed-order stages.
+constexpr int RR_CHUNKS = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_partial_kernel(const T *x, uint64_t cols, double *partials)
+{
+    __shared__ double sw[4];
+    const uint32_t row = blockIdx.y;
+    const uint32_t chunk = blockIdx.x;
+    const uint64_t per = (cols + RR_CHUNKS - 1) / RR_CHUNKS;
+    const uint64_t c0 = (uint64_t)chunk * per;
+    const uint64_t c1 = c0 + per < cols ? c0 + per : cols;
+    double acc = 0.0;
+    for (uint64_t c = c0 + threadIdx.x; c < c1; c += 256) acc += (double)x[(uint64_t)row * cols + c];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(uint64_t)row * RR_CHUNKS + chunk] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+}
+
+__global__ void row_final_kernel(const double *partials, double *out, uint32_t rows, double scale, int accumulate)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    double tot = 0.0;
+    for (int c = 0; c < RR_CHUNKS; ++c) tot += partials[(uint64_t)row * RR_CHUNKS + c];
+    tot *= scale;
+    out[row] = accumulate ? out[row] + tot : tot;
+}
+
+__global__ void set_double_kernel(double *dst, double v) { *dst = v; }
+
+} // namespace mcmc

@@ -1,0 +1,275 @@
+// xsection.hip -- Layer A of the xsection path: argument checks, kernel
+// selection and launches for InitSampleArray / WarmupMetropolis /
+// MCIntegrate_R2 / MCIntegrate_S_AB (xsection/src/main.cu:130-149,197,335) and
+// the device row means that replace the host Average of main.cu:221-223,359.
+#include "host_common.hpp"
+#include "xs_kernel.hpp"
+
+using namespace mcmc;
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t rowmean_bytes(uint32_t rows) { return align_up((size_t)rows * RR_CHUNKS * sizeof(double), 256); }
+
+int check_xs(const mcmc_xs_args *a)
+{
+    if (!a) return set_error(MCMC_EINVAL, "null args");
+    if (a->nNucleonsA + a->nNucleonsB == 0) return set_error(MCMC_EINVAL, "no nucleons");
+    if (a->nNucleonsA + a->nNucleonsB > 65535) return set_error(MCMC_EINVAL, "nNucleons must be <= 65535");
+    if (a->totalThreads == 0) return set_error(MCMC_EINVAL, "totalThreads must be > 0");
+    if (a->totalThreads > (1ull << 40)) return set_error(MCMC_EINVAL, "totalThreads must be <= 2^40");
+    if (!a->targets || !a->prevSample) return set_error(MCMC_EINVAL, "targets and prevSample must be device pointers");
+    if (a->accept_rule != MCMC_ACCEPT_RECIP && a->accept_rule != MCMC_ACCEPT_NODIV)
+        return set_error(MCMC_EINVAL, "xsection kernels implement MCMC_ACCEPT_RECIP and MCMC_ACCEPT_NODIV");
+    if (a->math_mode == MCMC_MATH_PRECISE && a->accept_rule != MCMC_ACCEPT_RECIP)
+        return set_error(MCMC_EINVAL, "precise math implements MCMC_ACCEPT_RECIP only");
+    if (a->math_mode != MCMC_MATH_PRECISE && a->math_mode != MCMC_MATH_FAST) return set_error(MCMC_EINVAL, "bad math_mode");
+    return MCMC_OK;
+}
+
+XsParams make_params(const mcmc_xs_args *a, uint32_t samples)
+{
+    XsParams p{};
+    p.T = a->totalThreads;
+    p.seed = a->seed;
+    p.step_offset = a->step_offset;
+    p.event_offset = a->event_offset;
+    p.inj_stride = a->injected_stride;
+    p.nA = a->nNucleonsA;
+    p.nB = a->nNucleonsB;
+    p.samples = samples;
+    p.stepsize = a->stepsize;
+    p.targets = a->targets;
+    p.prevSample = a->prevSample;
+    p.injected = a->injected;
+    // IntegrateSAB.cuh:10-12 in the reference's float arithmetic
+    const float PI = 3.141592653589f; // Common.cuh:21
+    p.G0 = a->sigmaNN / (4 * PI * a->beta);
+    p.twoBeta = 2.f * a->beta;
+    p.negk2 = -1.4426950408889634f / (2.0f * a->beta);
+    return p;
+}
+
+template <bool R2>
+int launch_chain_xs(const mcmc_xs_args *a, const XsParams &p, hipStream_t s)
+{
+    const dim3 grid((unsigned)((p.T + XS_BLOCK - 1) / XS_BLOCK), p.nA + p.nB);
+    const dim3 block(XS_BLOCK);
+    const bool inj = a->injected != nullptr;
+    if (a->math_mode == MCMC_MATH_PRECISE) {
+        if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_RECIP, MCMC_MATH_PRECISE, true, R2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_RECIP, MCMC_MATH_PRECISE, false, R2>), grid, block, 0, s, p);
+    } else if (a->accept_rule == MCMC_ACCEPT_RECIP) {
+        if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, true, R2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, false, R2>), grid, block, 0, s, p);
+    } else {
+        if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, true, R2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, false, R2>), grid, block, 0, s, p);
+    }
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+template <typename T>
+int row_reduce(const T *x, uint32_t rows, uint64_t cols, double scale, double *out, int accumulate, void *ws, size_t ws_bytes,
+               hipStream_t s)
+{
+    if (ws == nullptr || ws_bytes < rowmean_bytes(rows)) return set_error(MCMC_ENOMEM, "row reduction workspace too small");
+    hipLaunchKernelGGL((row_partial_kernel<T>), dim3(RR_CHUNKS, rows), dim3(256), 0, s, x, cols, (double *)ws);
+    MCMC_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(row_final_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, (const double *)ws, out, rows, scale,
+                       accumulate);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+// Lanes per event: the power of two in {4,16,64} with the least padded work.
+struct SabPlan {
+    int G;
+    size_t lds;
+};
+
+size_t sab_lds_bytes(int G, uint32_t nA, uint32_t nB)
+{
+    const size_t nN = (size_t)nA + nB;
+    const size_t epb = XS_BLOCK / G;
+    return align_up(sizeof(TgtLds) * nN, 16) + 3 * sizeof(float2) * epb * nN + sizeof(uint32_t) * epb * nA;
+}
+
+SabPlan sab_plan(uint32_t nA, uint32_t nB)
+{
+    const int cand[3] = {4, 16, 64};
+    SabPlan best{64, sab_lds_bytes(64, nA, nB)};
+    double best_cost = 1e300;
+    for (int G : cand) {
+        const size_t lds = sab_lds_bytes(G, nA, nB);
+        if (lds > 64 * 1024 && G != 64) continue; // keep >= 2 blocks per CU unless there is no choice
+        const double nN = (double)nA + nB;
+        const double mh = (double)((uint32_t)(nN + G - 1) / G) * 160.0;
+        double jb = 0;
+        for (uint32_t j0 = 0; j0 < nB;) {
+            const uint32_t rem = nB - j0;
+            const int w = rem > 2u * G ? 4 : (rem > (uint32_t)G ? 2 : 1);
+            jb += w;
+            j0 += w * G;
+        }
+        const double cost = G * (mh + nA * (jb * 10.0 + 4.0) + 12.0 * (G > 1 ? __builtin_ctz(G) : 0));
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = SabPlan{G, lds};
+        }
+    }
+    return best;
+}
+
+template <int G, int KIND>
+int launch_sab_g(const mcmc_xs_args *a, const XsParams &p, size_t lds, hipStream_t s)
+{
+    constexpr int EPB = XS_BLOCK / G;
+    const dim3 grid((unsigned)((p.T + EPB - 1) / EPB));
+    const dim3 block(XS_BLOCK);
+    const bool inj = a->injected != nullptr;
+#define MCMC_SAB_LAUNCH(RULE, MATH, INJ)                                                                         \
+    do {                                                                                                         \
+        auto k = sab_kernel<G, KIND, RULE, MATH, INJ>;                                                           \
+        if (lds > 48 * 1024)                                                                                     \
+            MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k, grid, block, lds, s, p);                                                           \
+    } while (0)
+    if (a->math_mode == MCMC_MATH_PRECISE) {
+        if (inj) MCMC_SAB_LAUNCH(MCMC_ACCEPT_RECIP, MCMC_MATH_PRECISE, true);
+        else MCMC_SAB_LAUNCH(MCMC_ACCEPT_RECIP, MCMC_MATH_PRECISE, false);
+    } else if (a->accept_rule == MCMC_ACCEPT_RECIP) {
+        if (inj) MCMC_SAB_LAUNCH(MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, true);
+        else MCMC_SAB_LAUNCH(MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, false);
+    } else {
+        if (inj) MCMC_SAB_LAUNCH(MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, true);
+        else MCMC_SAB_LAUNCH(MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, false);
+    }
+#undef MCMC_SAB_LAUNCH
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+template <int G>
+int launch_sab_kind(const mcmc_xs_args *a, const XsParams &p, size_t lds, bool all_r2ws, hipStream_t s)
+{
+    if (all_r2ws) return launch_sab_g<G, MCMC_TARGET_R2WS>(a, p, lds, s);
+    return launch_sab_g<G, -1>(a, p, lds, s);
+}
+
+} // namespace
+
+extern "C" size_t mcmc_row_mean_workspace_bytes(uint32_t rows, uint64_t) { return rowmean_bytes(rows); }
+
+extern "C" size_t mcmc_xs_workspace_bytes(const mcmc_xs_args *a)
+{
+    if (!a) return 0;
+    const uint32_t nN = a->nNucleonsA + a->nNucleonsB;
+    return rowmean_bytes(nN < 4 ? 4 : nN) + align_up(3 * sizeof(uint32_t) * a->totalThreads, 256);
+}
+
+extern "C" int mcmc_launch_init_sample_array(float *prevSample, float initSample, uint32_t nNucleons, uint64_t totalThreads,
+                                             void *stream)
+{
+    if (!prevSample) return set_error(MCMC_EINVAL, "prevSample is null");
+    const uint64_t total = (uint64_t)nNucleons * totalThreads;
+    if (total == 0) return set_error(MCMC_EINVAL, "empty sample array");
+    hipLaunchKernelGGL(init_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       prevSample, initSample, total);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_launch_warmup_metropolis(const mcmc_xs_args *a, uint32_t iterations, void *stream)
+{
+    int rc = check_xs(a);
+    if (rc) return rc;
+    if (a->injected && a->injected_stride < (uint64_t)iterations * (a->nNucleonsA + a->nNucleonsB) * 2)
+        return set_error(MCMC_EINVAL, "injected_stride too small for iterations * nNucleons * 2 draws");
+    const XsParams p = make_params(a, iterations);
+    if (iterations == 0) return MCMC_OK;
+    return launch_chain_xs<false>(a, p, (hipStream_t)stream);
+}
+
+extern "C" int mcmc_launch_integrate_r2(const mcmc_xs_args *a, float *resultBuffer, uint32_t samples, double *runMean,
+                                        void *stream)
+{
+    int rc = check_xs(a);
+    if (rc) return rc;
+    if (!resultBuffer) return set_error(MCMC_EINVAL, "resultBuffer is null");
+    if (samples == 0) return set_error(MCMC_EINVAL, "samples must be > 0");
+    const uint32_t nN = a->nNucleonsA + a->nNucleonsB;
+    if (a->injected && a->injected_stride < (uint64_t)samples * nN * 2)
+        return set_error(MCMC_EINVAL, "injected_stride too small for samples * nNucleons * 2 draws");
+    XsParams p = make_params(a, samples);
+    p.result = resultBuffer;
+    rc = launch_chain_xs<true>(a, p, (hipStream_t)stream);
+    if (rc) return rc;
+    if (runMean)
+        return row_reduce<float>(resultBuffer, nN, a->totalThreads, 1.0 / (double)a->totalThreads, runMean, 0, a->workspace,
+                                 a->workspace_bytes, (hipStream_t)stream);
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuffer, uint32_t samples, float impactParameter,
+                                         double *runMean, double *hits, float dmax2, void *stream)
+{
+    int rc = check_xs(a);
+    if (rc) return rc;
+    if (!resultBuffer) return set_error(MCMC_EINVAL, "resultBuffer is null");
+    if (samples == 0) return set_error(MCMC_EINVAL, "samples must be > 0");
+    if (a->nNucleonsA == 0 || a->nNucleonsB == 0) return set_error(MCMC_EINVAL, "both nuclei need at least one nucleon");
+    const uint32_t nN = a->nNucleonsA + a->nNucleonsB;
+    if (a->injected && a->injected_stride < (uint64_t)samples * nN * 4)
+        return set_error(MCMC_EINVAL, "injected_stride too small for samples * nNucleons * 4 draws");
+    if (!(a->beta > 0.0f)) return set_error(MCMC_EINVAL, "beta must be > 0");
+    if ((runMean || hits) && (!a->workspace || a->workspace_bytes < mcmc_xs_workspace_bytes(a)))
+        return set_error(MCMC_ENOMEM, "workspace smaller than mcmc_xs_workspace_bytes()");
+    hipStream_t s = (hipStream_t)stream;
+
+    XsParams p = make_params(a, samples);
+    p.result = resultBuffer;
+    p.b = impactParameter;
+    p.dmax2 = dmax2;
+    p.do_hits = hits != nullptr;
+    uint32_t *hitbuf = nullptr;
+    if (hits) {
+        hitbuf = (uint32_t *)((char *)a->workspace + rowmean_bytes(nN < 4 ? 4 : nN));
+        p.hits = hitbuf;
+    }
+
+    // `targets` is a device array, so the caller says whether one kind covers all nucleons.
+    const bool all_r2ws = a->uniform_kind == MCMC_TARGET_R2WS;
+
+    const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB);
+    if (plan.lds > 160 * 1024) return set_error(MCMC_EINVAL, "nuclei too large for the LDS-resident S_AB kernel (A+B <= ~1600)");
+    switch (plan.G) {
+    case 4: rc = launch_sab_kind<4>(a, p, plan.lds, all_r2ws, s); break;
+    case 16: rc = launch_sab_kind<16>(a, p, plan.lds, all_r2ws, s); break;
+    default: rc = launch_sab_kind<64>(a, p, plan.lds, all_r2ws, s); break;
+    }
+    if (rc) return rc;
+    if (runMean) {
+        rc = row_reduce<float>(resultBuffer, 1, a->totalThreads, 1.0 / (double)a->totalThreads, runMean, 0, a->workspace,
+                               a->workspace_bytes, s);
+        if (rc) return rc;
+    }
+    if (hits) {
+        rc = row_reduce<uint32_t>(hitbuf, 3, a->totalThreads, 1.0, hits, 0, a->workspace, a->workspace_bytes, s);
+        if (rc) return rc;
+        // hits[3] = number of event samples
+        hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, s, hits + 3, (double)a->totalThreads * (double)samples);
+        MCMC_HIP_CHECK(hipGetLastError());
+    }
+    return MCMC_OK;
+}
+
+extern "C" int mcmc_launch_row_mean_f32(const float *x, uint32_t rows, uint64_t cols, double *out, void *workspace,
+                                        size_t workspace_bytes, void *stream)
+{
+    if (!x || !out || rows == 0 || cols == 0) return set_error(MCMC_EINVAL, "bad row_mean arguments");
+    return row_reduce<float>(x, rows, cols, 1.0 / (double)cols, out, 0, workspace, workspace_bytes, (hipStream_t)stream);
+}
