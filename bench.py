@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- MH proposals/sec of the many-chain Metropolis-Hastings kernel.
+
+One "step" = one launch of the hot path over one batch: `--sweeps` MH sweeps of
+every chain (2^24 chains x 3 independent r^2 Woods-Saxon(2.0, 0.54) coordinates
+per GPU, the 3-D target of BASELINE.json configs[1] at the chain count the
+metric is quoted on), with the streaming sufficient statistics (sum, sum of
+squares, accepts) reduced on the device; for N > 1 followed by ONE RCCL
+all-reduce of the statistics vector (the path's only exchange step).  Chains are
+sharded by global chain id (Philox counter), so results do not depend on N.
+
+Prints ONE JSON line (see the driver contract in the task statement) with
+`roofline` (FP32 VALU bound: SURVEY.md 8d) and `cpu_baseline` (the oracle's
+restatement of the reference step logic timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PROPOSAL = 24.0      # algorithmic FP32 flop per 1-D r^2 WS proposal
+VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=1 << 24, help="chains per GPU")
+    ap.add_argument("--coords", type=int, default=3)
+    ap.add_argument("--sweeps", type=int, default=256, help="MH sweeps per step (launch)")
+    ap.add_argument("--step-size", type=float, default=2.48,
+                    help="proposal width (2.48 = max-efficiency width of stepsize/results/r2WS_2.0_0.54.png)")
+    ap.add_argument("--rule", default="recip", choices=["recip", "nodiv", "log"])
+    ap.add_argument("--math", default="fast", choices=["fast", "precise"])
+    ap.add_argument("--lags", type=int, default=0, help="lag products inside the timed kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-ess", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, seconds):
+    """The oracle's FP32 restatement of Metropolis.cuh:40-52 (+ the library's Philox draws and the
+    same three accumulators), one thread per core share; bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    orc = O.Oracle()
+    cores = min(16, os.cpu_count() or 1)
+    sweeps = args.sweeps
+    t0 = time.perf_counter()
+    orc.baseline_chains_f32(0, 64, args.coords, O.R2WS, 2.0, 0.54, args.step_size, 314159265, 0, sweeps)
+    probe = time.perf_counter() - t0
+    per_chain = probe / 64
+    chains_per_thread = max(16, int(seconds / per_chain))
+
+    def work(i):
+        return orc.baseline_chains_f32(i * chains_per_thread, chains_per_thread, args.coords, O.R2WS, 2.0, 0.54,
+                                       args.step_size, 314159265, 0, sweeps)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    proposals = cores * chains_per_thread * args.coords * sweeps
+    return {"value": proposals / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
+            "sample": f"{cores * chains_per_thread} chains x {args.coords} coords x {sweeps} sweeps "
+                      f"(oracle/mcmc_oracle.c orc_baseline_chains_f32, one thread per core, {dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mcmc_amd import api, lib as L
+    rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "log": L.ACCEPT_LOG}[args.rule]
+    math = L.MATH_FAST if args.math == "fast" else L.MATH_PRECISE
+    target = api.make_target(L.TARGET_R2WS, 2.0, 0.54)   # PDF(), metropolis.hpp:19-23 / main.cu:14-19
+    eng = api.ChainEngine(args.chains, args.coords, target, args.step_size, precision=32, accept_rule=rule,
+                          math_mode=math, n_lags=args.lags, seed=314159265, x0=1.0,
+                          chain_offset=rank * args.chains, center=2.3, device=dev)
+
+    def step():
+        st = eng.run(args.sweeps, window_start=True)
+        if dist is not None:
+            dist.all_reduce(st)        # the one collective per batch: sufficient statistics only
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record()
+        st = eng.run(args.sweeps, window_start=True)
+        evs[i][1].record()
+        if dist is not None:
+            dist.all_reduce(st)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
+
+    proposals_per_step = world * args.chains * args.coords * args.sweeps
+    value = proposals_per_step * args.steps / elapsed
+    summ = eng.summary(stats_host=st.cpu().numpy(), n_chains=world * args.chains, n_steps=args.sweeps)
+
+    out = None
+    if rank == 0:
+        launch_props = args.chains * args.coords * args.sweeps
+        achieved = FLOP_PER_PROPOSAL * launch_props / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "MH proposals/sec", "value": value, "unit": "proposals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"mh_chain r2WoodsSaxon(2.0,0.54) x{args.coords} coords, "
+                                   f"{args.chains} chains/GPU, {args.sweeps} sweeps/launch, step {args.step_size}",
+                       "chains_per_gpu": args.chains, "coords": args.coords, "sweeps_per_step": args.sweeps,
+                       "accept_rule": args.rule, "math": args.math, "lags_in_kernel": args.lags,
+                       "rng": "philox4x32-10", "parallelism": f"chains sharded over {world} GPU(s)"},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "mcmc::chain_kernel", "kernel_ms": kernel_ms,
+                         "flop_per_proposal": FLOP_PER_PROPOSAL, "proposals_per_launch": launch_props,
+                         "note": "FP32 VALU-bound (state in registers, no per-step HBM traffic); algorithmic flop "
+                                 "count excludes Philox integer work; HBM traffic per launch = state load/store only"},
+            "estimates": {"mean_r": summ[0]["mean"], "var_r": summ[0]["variance"],
+                          "acceptance": summ[0]["acceptance"]},
+        }
+    # ESS/sec: tau_int from a lag-49 window at the same width on a chain subset (not timed)
+    if not args.no_ess:
+        sub = min(args.chains, 1 << 20)
+        e2 = api.ChainEngine(sub, 1, target, args.step_size, precision=32, accept_rule=rule, math_mode=math,
+                             n_lags=L.MAX_LAGS, seed=314159265, x0=1.0, chain_offset=rank * args.chains, center=2.3,
+                             device=dev)
+        e2.run(512, n_lags=0)
+        e2.run(2048, window_start=True, n_lags=L.MAX_LAGS)
+        torch.cuda.synchronize()
+        tau = e2.summary()[0]["tau_int"]
+        if out is not None:
+            out["ess_per_sec"] = value / tau
+            out["tau_int"] = tau
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

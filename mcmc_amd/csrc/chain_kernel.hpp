@@ -183,7 +183,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
                 for (int k = 0; k < NL; ++k) {
                     if (k < (int)p.n_lags) {
                         // hist[k] = y_{n_lags-1-k}
-                        const float w = wave_sum_f32(valid ? (float)hist[k] : 0.0f);
+                        const double w = wave_sum(valid ? (double)hist[k] : 0.0);
                         if (lane == 0) sred[wave][3 + p.n_lags + (p.n_lags - 1 - k)] += (double)w;
                     }
                 }
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
 #pragma unroll
             for (int k = 0; k < NL; ++k) {
                 if (k < (int)p.n_lags) {
-                    const float pk = wave_sum_f32(valid ? P[k] : 0.0f);
-                    const float zk = wave_sum_f32(valid ? (float)hist[k] : 0.0f);
+                    const double pk = wave_sum(valid ? (double)P[k] : 0.0);
+                    const double zk = wave_sum(valid ? (double)hist[k] : 0.0);
                     if (lane == 0) {
                         sred[wave][3 + k] += (double)pk;
                         sred[wave][3 + 2 * p.n_lags + k] += (double)zk;

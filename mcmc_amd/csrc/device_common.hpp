@@ -206,9 +206,9 @@ template <int KIND, int RULE, int MATH>
 __device__ __forceinline__ bool mh_step(const Target<float> &t, float &x, float &aux, float step, float normal,
                                         float uniform)
 {
-    float next;
-    if constexpr (MATH == MCMC_MATH_FAST) next = __builtin_fmaf(step, normal, x);
-    else next = x + step * normal; // Metropolis.cuh:43
+    // Metropolis.cuh:43.  Deliberately mul + add (two roundings) in every mode: with a fused
+    // multiply-add the positions drift from the reference arithmetic by an ulp per accepted step.
+    const float next = x + step * normal;
     bool take;
     if constexpr (RULE == MCMC_ACCEPT_RECIP) {
         const float pn = pdf_eval<KIND, MATH>(t, next);

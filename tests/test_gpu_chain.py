@@ -1,0 +1,215 @@
+"""GPU parity tests of the many-chain MH kernel (mcmc_chain_run) against the CPU
+oracle, through the C ABI.  Bars (BASELINE.json north_star): under identical
+injected draws accept/reject bits are identical and positions agree to 1e-6
+relative; estimates agree with known answers within 3 combined standard errors.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+R2WS_REF = (O.R2WS, 2.0, 0.54)      # PDF(), stepsize/include/metropolis.hpp:19-23
+R2GAUSS_1 = (O.R2GAUSS, 1.0, 0.0)   # metropolis.hpp:24-25 (commented alternative), BASELINE config 0
+
+
+def _engine(dev, **kw):
+    from mcmc_amd import api, lib as L
+    tk, p0, p1 = kw.pop("target")
+    return api.ChainEngine(target=api.make_target(tk, p0, p1), device=dev, **kw)
+
+
+@pytest.mark.parametrize("target", [R2WS_REF, R2GAUSS_1])
+@pytest.mark.parametrize("step", [0.5, 2.5, 5.0])
+def test_fp64_cpu_rule_injected_matches_a1(dev, oracle, target, step):
+    """a1: metropolis.hpp:28-50 with injected draws; FP64, short-circuit rule,
+    uniforms consumed through a per-chain cursor."""
+    from mcmc_amd import lib as L
+    n_steps, n_chains = 4096, 5
+    rng = np.random.default_rng(1234)
+    normals = rng.standard_normal((n_steps, 1, n_chains))
+    uniforms = rng.random((n_steps, 1, n_chains))
+    eng = _engine(dev, n_chains=n_chains, n_coords=1, target=target, step=step, precision=64,
+                  accept_rule=L.ACCEPT_SHORTCIRCUIT, math_mode=L.MATH_PRECISE)
+    samples = torch.empty((n_steps, 1, n_chains), dtype=torch.float64, device=dev)
+    bits = torch.zeros((n_steps, 1, n_chains), dtype=torch.uint8, device=dev)
+    eng.run(n_steps, samples=samples, inj_normals=torch.from_numpy(normals).to(dev),
+            inj_uniforms=torch.from_numpy(uniforms).to(dev), accept_bits=bits)
+    torch.cuda.synchronize()
+    s, b = samples.cpu().numpy(), bits.cpu().numpy()
+    summ = eng.summary()
+    tot_acc = 0
+    for c in range(n_chains):
+        acc, ref_s, ref_b, used = oracle.mh_chain_f64(n_steps, step, target[0], target[1], target[2], 1.0,
+                                                       normals[:, 0, c], uniforms[:, 0, c])
+        assert np.array_equal(b[:, 0, c], ref_b), f"accept bits differ for chain {c}"
+        np.testing.assert_allclose(s[:, 0, c], ref_s, rtol=1e-12, atol=0)
+        tot_acc += acc
+    assert summ[0]["acceptance"] == pytest.approx(tot_acc / (n_steps * n_chains), abs=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast"])
+@pytest.mark.parametrize("target", [R2WS_REF, R2GAUSS_1, (O.WS, 2.0, 0.54), (O.GAUSS, 1.5, 0.0)])
+def test_fp32_gpu_rule_injected_matches_a5(dev, oracle, mode, target):
+    """a5/a7: Metropolis.cuh:40-52 with injected draws, n_coords coordinates per
+    chain (the Gibbs sweep); accept bits identical, positions to 1e-6."""
+    from mcmc_amd import lib as L
+    rule, math = {"recip_precise": (L.ACCEPT_RECIP, L.MATH_PRECISE), "recip_fast": (L.ACCEPT_RECIP, L.MATH_FAST),
+                  "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST)}[mode]
+    n_steps, n_chains, n_coords, step = 1024, 7, 3, 2.2
+    rng = np.random.default_rng(99)
+    normals = rng.standard_normal((n_steps, n_coords, n_chains)).astype(np.float32)
+    uniforms = (1.0 - rng.random((n_steps, n_coords, n_chains))).astype(np.float32)  # (0,1]
+    eng = _engine(dev, n_chains=n_chains, n_coords=n_coords, target=target, step=step, precision=32,
+                  accept_rule=rule, math_mode=math)
+    samples = torch.empty((n_steps, n_coords, n_chains), dtype=torch.float32, device=dev)
+    bits = torch.zeros((n_steps, n_coords, n_chains), dtype=torch.uint8, device=dev)
+    eng.run(n_steps, samples=samples, inj_normals=torch.from_numpy(normals).to(dev),
+            inj_uniforms=torch.from_numpy(uniforms).to(dev), accept_bits=bits)
+    torch.cuda.synchronize()
+    s, b = samples.cpu().numpy(), bits.cpu().numpy()
+    tg = [target] * n_coords
+    strict = 0
+    for c in range(n_chains):
+        draws = np.stack([normals[:, :, c], uniforms[:, :, c]], axis=-1)  # [step][coord][2]
+        x, ref_b, trace, margin = oracle.warmup_thread_trace(tg, [1.0] * n_coords, step, n_steps, draws)
+        # a run that never comes within 1e-5 of an accept/reject tie cannot flip on last-ulp differences of expf
+        if margin > 1e-5:
+            assert np.array_equal(b[:, :, c], ref_b), f"accept bits differ for chain {c} (margin {margin})"
+            np.testing.assert_allclose(s[:, :, c], trace, rtol=1e-6, atol=0)
+            strict += 1
+    assert strict >= n_chains - 3, "too many chains passed within 1e-5 of a tie to be checked bit for bit"
+    final = eng.state.cpu().numpy()
+    np.testing.assert_allclose(final, s[-1], rtol=0, atol=0)
+
+
+def test_philox_draws_match_oracle(dev, oracle):
+    """RNG layer: device Philox + Box-Muller vs the oracle's independent restatement."""
+    from mcmc_amd import lib as L
+    n_chains, n_steps, coord, seed, off = 64, 33, 2, 314159265, 7
+    for math, tol in ((L.MATH_PRECISE, 2e-6), (L.MATH_FAST, 2e-5)):
+        bufs = [torch.zeros((n_steps, n_chains), dtype=torch.float32, device=dev) for _ in range(4)]
+        L.check(L.lib.mcmc_launch_draws(seed, 1000, n_chains, coord, off, n_steps, math,
+                                        *[C.c_void_p(t.data_ptr()) for t in bufs], None))
+        torch.cuda.synchronize()
+        z, u, a0, a1 = [t.cpu().numpy() for t in bufs]
+        for c in (0, 5, 63):
+            for i in range(n_steps):
+                zn, un = oracle.mh_draws_f32(seed, 1000 + c, coord, off + i)
+                b0, b1 = oracle.angle_draws_f32(seed, 1000 + c, coord, off + i)
+                assert u[i, c] == un and a0[i, c] == b0 and a1[i, c] == b1  # integer -> float path is exact
+                assert abs(z[i, c] - zn) <= tol * max(1.0, abs(zn))
+
+
+def test_philox_mode_trajectory_matches_oracle_on_device_draws(dev, oracle):
+    """Philox mode == injected mode fed with the library's own draws (logic parity at any seed)."""
+    from mcmc_amd import lib as L
+    n_chains, n_steps, seed = 64, 200, 42
+    z = torch.zeros((n_steps, n_chains), dtype=torch.float32, device=dev)
+    u = torch.zeros((n_steps, n_chains), dtype=torch.float32, device=dev)
+    L.check(L.lib.mcmc_launch_draws(seed, 0, n_chains, 0, 0, n_steps, L.MATH_PRECISE, C.c_void_p(z.data_ptr()),
+                                    C.c_void_p(u.data_ptr()), None, None, None))
+    eng = _engine(dev, n_chains=n_chains, n_coords=1, target=R2WS_REF, step=2.2, precision=32,
+                  accept_rule=L.ACCEPT_RECIP, math_mode=L.MATH_PRECISE, seed=seed)
+    samples = torch.empty((n_steps, 1, n_chains), dtype=torch.float32, device=dev)
+    bits = torch.zeros((n_steps, 1, n_chains), dtype=torch.uint8, device=dev)
+    eng.run(n_steps, samples=samples, accept_bits=bits)
+    torch.cuda.synchronize()
+    zc, uc, s, b = z.cpu().numpy(), u.cpu().numpy(), samples.cpu().numpy(), bits.cpu().numpy()
+    for c in range(0, n_chains, 9):
+        draws = np.stack([zc[:, c], uc[:, c]], axis=-1).reshape(n_steps, 1, 2)
+        x, ref_b, trace, margin = oracle.warmup_thread_trace([R2WS_REF], [1.0], 2.2, n_steps, draws)
+        if margin > 1e-5:
+            assert np.array_equal(b[:, 0, c], ref_b[:, 0])
+            np.testing.assert_allclose(s[:, 0, c], trace[:, 0], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n_chains", [1, 3])
+def test_streaming_statistics_match_a4(dev, oracle, n_chains):
+    """a4: statistics.hpp:6-57 from the streaming accumulators; n_chains == 1 is
+    the reference's case, n_chains > 1 the pooled generalisation."""
+    from mcmc_amd import lib as L
+    n_steps, n_lags = 5000, 49
+    eng = _engine(dev, n_chains=n_chains, n_coords=1, target=R2WS_REF, step=2.5, precision=64,
+                  accept_rule=L.ACCEPT_SHORTCIRCUIT, math_mode=L.MATH_PRECISE, n_lags=n_lags, center=2.3)
+    samples = torch.empty((n_steps, 1, n_chains), dtype=torch.float64, device=dev)
+    eng.run(n_steps, samples=samples)
+    torch.cuda.synchronize()
+    s = samples.cpu().numpy()[:, 0, :]
+    summ = eng.summary()[0]
+    if n_chains == 1:
+        x = s[:, 0]
+        assert summ["mean"] == pytest.approx(oracle.average_f64(x), rel=1e-6)
+        assert summ["variance"] == pytest.approx(oracle.variance_f64(x), rel=1e-5)
+        for k in range(1, n_lags + 1):
+            assert summ["rho"][k - 1] == pytest.approx(oracle.autocorrelation_f64(x, k), abs=2e-5)
+    else:
+        N = s.size
+        mu = s.mean()
+        var = ((s - mu) ** 2).sum() / (N - 1)
+        assert summ["mean"] == pytest.approx(mu, rel=1e-6)
+        assert summ["variance"] == pytest.approx(var, rel=1e-5)
+        for k in (1, 2, 10, 49):
+            cov = ((s[:-k] - mu) * (s[k:] - mu)).sum() / (n_chains * (n_steps - k) - 1)
+            assert summ["rho"][k - 1] == pytest.approx(cov / var, abs=2e-5)
+
+
+def test_split_launches_and_chain_partition_are_invariant(dev):
+    """Counter-based RNG: (a) one launch of n steps == two launches of n/2 (+ring carry);
+    (b) chains [0,N) on one device == two half partitions with chain_offset (the multi-GPU sharding)."""
+    from mcmc_amd import lib as L
+    N, n, n_lags = 1000, 300, 16
+    kw = dict(n_coords=2, target=R2WS_REF, step=2.2, precision=32, accept_rule=L.ACCEPT_RECIP, math_mode=L.MATH_FAST,
+              n_lags=n_lags, center=2.3, seed=7)
+    a = _engine(dev, n_chains=N, **kw)
+    sa = a.run(n).clone()
+    b = _engine(dev, n_chains=N, carry_ring=True, **kw)
+    s1 = b.run(150, window_start=True).clone()
+    s2 = b.run(150, window_start=False).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a.state, b.state)
+    core = 3 + n_lags
+    np.testing.assert_allclose((s1 + s2)[:, :core].cpu().numpy(), sa[:, :core].cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(s1[:, core:core + n_lags].cpu().numpy(), sa[:, core:core + n_lags].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(s2[:, core + n_lags:].cpu().numpy(), sa[:, core + n_lags:].cpu().numpy(), rtol=1e-6)
+    # partition
+    h0 = _engine(dev, n_chains=N // 2, chain_offset=0, **kw)
+    h1 = _engine(dev, n_chains=N // 2, chain_offset=N // 2, **kw)
+    t0 = h0.run(n).clone()
+    t1 = h1.run(n).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([h0.state, h1.state], dim=1), a.state)
+    np.testing.assert_allclose((t0 + t1).cpu().numpy(), sa.cpu().numpy(), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("mode", ["recip_fast", "nodiv_fast", "log_fast", "recip_precise"])
+def test_known_answer_r2ws_large(dev, mode):
+    """Full-size property test: 2^20 chains x 3 coords; <r^2> of r^2 WS(2.0,0.54) = 6.424247."""
+    from mcmc_amd import lib as L
+    rule, math = {"recip_precise": (L.ACCEPT_RECIP, L.MATH_PRECISE), "recip_fast": (L.ACCEPT_RECIP, L.MATH_FAST),
+                  "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "log_fast": (L.ACCEPT_LOG, L.MATH_FAST)}[mode]
+    N, n = 1 << 20, 400
+    eng = _engine(dev, n_chains=N, n_coords=3, target=R2WS_REF, step=2.2, precision=32, accept_rule=rule,
+                  math_mode=math, n_lags=0, center=0.0)
+    eng.run(300)  # warm-up
+    eng.run(n)
+    torch.cuda.synchronize()
+    for c, sm in enumerate(eng.summary()):
+        ex2 = sm["variance"] + sm["mean"] ** 2
+        # sd(x^2) ~ 5.3; tau_int(x^2) < 10 at step 2.2 -> 3 sigma < 3*5.3*sqrt(2*10/(N*n)) = 3.5e-3
+        assert abs(ex2 - 6.424247) < 3.5e-3, (mode, c, ex2)
+        assert 0.40 < sm["acceptance"] < 0.50
+
+
+def test_argument_errors(dev):
+    from mcmc_amd import api, lib as L
+    eng = _engine(dev, n_chains=10, n_coords=1, target=R2WS_REF, step=1.0, n_lags=10)
+    with pytest.raises(L.McmcError):
+        eng.run(5)  # window start needs n_steps >= n_lags
+    eng.args.workspace_bytes = 0
+    with pytest.raises(L.McmcError):
+        eng.run(50)

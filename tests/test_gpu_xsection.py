@@ -1,0 +1,195 @@
+"""GPU parity tests of the xsection path (WarmupMetropolis, MCIntegrate_R2,
+MCIntegrate_S_AB, black-disk hits, run estimator) against the CPU oracle,
+through the C ABI.  Injected draw streams follow the reference's consumption
+order (Metropolis.cuh:43,47; IntegrateSAB.cuh:50-52)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+WS20 = (O.R2WS, 2.0, 0.54)  # main.cu:14-19
+
+
+def _modes():
+    from mcmc_amd import lib as L
+    return {"recip_precise": (L.ACCEPT_RECIP, L.MATH_PRECISE), "recip_fast": (L.ACCEPT_RECIP, L.MATH_FAST),
+            "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST)}
+
+
+def _xs(dev, nA, nB, T, targets, mode="recip_precise", **kw):
+    from mcmc_amd import api
+    rule, math = _modes()[mode]
+    return api.XsEngine(nA, nB, T, targets, accept_rule=rule, math_mode=math, device=dev, **kw)
+
+
+def _draws(rng, T, L):
+    """Per-thread streams of alternating (normal, uniform in (0,1])."""
+    d = np.empty((T, L), dtype=np.float32)
+    d[:, 0::2] = rng.standard_normal((T, L // 2)).astype(np.float32)
+    d[:, 1::2] = (1.0 - rng.random((T, L // 2))).astype(np.float32)
+    return d
+
+
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast"])
+@pytest.mark.parametrize("nN", [1, 3, 8])
+def test_warmup_and_r2_injected(dev, oracle, mode, nN):
+    """a8 + a10: final state and per-thread Kahan means of r^2 (IntegrateR2.cuh:33-52)."""
+    T, iters, samples, step = 70, 40, 64, 2.2
+    targets = [WS20 if n % 2 == 0 else (O.R2WS, 2.54, 0.5) for n in range(nN)]
+    rng = np.random.default_rng(5 + nN)
+    d1 = _draws(rng, T, iters * nN * 2)
+    d2 = _draws(rng, T, samples * nN * 2)
+    xs = _xs(dev, nN, 0, T, targets, mode)
+    xs.WarmupMetropolis(iters, stepsize=step, injected=torch.from_numpy(d1).to(dev))
+    torch.cuda.synchronize()
+    st1 = xs.prevSample.cpu().numpy().copy()
+    res, run_mean = xs.MCIntegrate_R2(samples, injected=torch.from_numpy(d2).to(dev))
+    torch.cuda.synchronize()
+    st2, res, run_mean = xs.prevSample.cpu().numpy(), res.cpu().numpy(), run_mean.cpu().numpy()
+    strict = 0
+    for e in range(T):
+        x1, _, _, m1 = oracle.warmup_thread_trace(targets, [1.0] * nN, step, iters, d1[e])
+        _, _, _, m2 = oracle.warmup_thread_trace(targets, x1, step, samples, d2[e])
+        x2, out = oracle.integrate_r2_thread(targets, x1, step, samples, d2[e])
+        if min(m1, m2) <= 1e-5:
+            continue
+        strict += 1
+        np.testing.assert_allclose(st1[:, e], x1, rtol=1e-6)
+        np.testing.assert_allclose(st2[:, e], x2, rtol=1e-6)
+        np.testing.assert_allclose(res[:, e], out, rtol=2e-6)
+    assert strict >= T * 0.8
+    # device run mean (replaces host Average, main.cu:221-223) vs the oracle's FP32 Kahan average
+    for n in range(nN):
+        assert run_mean[n] == pytest.approx(oracle.average_f32(res[n]), rel=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast"])
+@pytest.mark.parametrize("nA,nB", [(2, 2), (4, 4), (3, 5), (12, 12), (16, 20), (70, 70)])
+@pytest.mark.parametrize("b", [0.0, 1.5])
+def test_sab_injected(dev, oracle, mode, nA, nB, b):
+    """a12: per-thread Kahan mean of prod (1 - Gamma), plus black-disk hit counters."""
+    nN = nA + nB
+    T = 37 if nN < 60 else 9
+    samples, step = (17 if nN < 60 else 6), 2.2
+    targets = [WS20] * nN
+    rng = np.random.default_rng(nA * 100 + nB)
+    L = samples * nN * 4
+    d = np.empty((T, L), dtype=np.float32)
+    blk = d.reshape(T, samples, 2, nN, 2)
+    blk[:, :, 0, :, 0] = rng.standard_normal((T, samples, nN))
+    blk[:, :, 0, :, 1] = 1.0 - rng.random((T, samples, nN))
+    blk[:, :, 1, :, :] = 1.0 - rng.random((T, samples, nN, 2))
+    dmax2 = 4.3 / np.pi  # d < 2 r_N with pi (2 r_N)^2 /4... black disk: sigma_NN = pi d_max^2
+    xs = _xs(dev, nA, nB, T, targets, mode)
+    res, mean, hits = xs.MCIntegrate_S_AB(samples, b, stepsize=step, injected=torch.from_numpy(d).to(dev), dmax2=dmax2)
+    torch.cuda.synchronize()
+    res, mean, hits, st = res.cpu().numpy(), mean.cpu().numpy(), hits.cpu().numpy(), xs.prevSample.cpu().numpy()
+    tot = np.zeros(3)
+    strict = 0
+    all_ok = True
+    for e in range(T):
+        mh = d[e].reshape(samples, 2, nN, 2)[:, 0].reshape(samples, nN * 2)
+        _, _, _, margin = oracle.warmup_thread_trace(targets, [1.0] * nN, step, samples, mh)
+        x, m, h, _ = oracle.integrate_sab_thread(nA, nB, targets, [1.0] * nN, step, samples, b, d[e], dmax2=dmax2)
+        tot += h
+        if margin <= 1e-5:
+            all_ok = False
+            continue
+        strict += 1
+        np.testing.assert_allclose(st[:, e], x, rtol=1e-6)
+        tol = 2e-5 if mode == "recip_precise" else 2e-4
+        assert res[e] == pytest.approx(m, rel=tol, abs=1e-7), (e, res[e], m)
+    assert strict >= T * 0.7
+    assert mean[0] == pytest.approx(res.astype(np.float64).mean(), rel=1e-12)
+    assert hits[3] == T * samples
+    if all_ok:
+        # hit flags compare d^2 < dmax2 on positions equal to ~1e-7: allow a few borderline pairs
+        assert abs(hits[0] - tot[0]) <= max(2, 1e-4 * tot[0])
+        assert abs(hits[1] - tot[1]) <= 1
+        assert abs(hits[2] - tot[2]) <= max(2, 1e-4 * tot[2])
+
+
+def test_sab_philox_matches_oracle_on_device_draws(dev, oracle):
+    """Philox mode == injected mode fed with the library's own draws (He-4 + He-4, main.cu:38-41)."""
+    from mcmc_amd import lib as L
+    nA = nB = 4
+    nN, T, samples, seed, b = 8, 16, 10, 99, 0.7
+    per = []
+    for n in range(nN):
+        bufs = [torch.zeros((samples, T), dtype=torch.float32, device=dev) for _ in range(4)]
+        L.check(L.lib.mcmc_launch_draws(seed, 0, T, n, 0, samples, L.MATH_PRECISE,
+                                        *[C.c_void_p(t.data_ptr()) for t in bufs], None))
+        per.append([t.cpu().numpy() for t in bufs])
+    torch.cuda.synchronize()
+    d = np.empty((T, samples, 2, nN, 2), dtype=np.float32)
+    for n in range(nN):
+        z, u, a0, a1 = per[n]
+        d[:, :, 0, n, 0] = z.T
+        d[:, :, 0, n, 1] = u.T
+        d[:, :, 1, n, 0] = a0.T
+        d[:, :, 1, n, 1] = a1.T
+    d = d.reshape(T, -1)
+    xs = _xs(dev, nA, nB, T, [WS20] * nN, "recip_precise", seed=seed)
+    res, mean, _ = xs.MCIntegrate_S_AB(samples, b, stepsize=2.2)
+    torch.cuda.synchronize()
+    res = res.cpu().numpy()
+    for e in range(T):
+        x, m, _, _ = oracle.integrate_sab_thread(nA, nB, [WS20] * nN, [1.0] * nN, 2.2, samples, b, d[e])
+        assert res[e] == pytest.approx(m, rel=2e-5, abs=1e-7)
+
+
+def test_gamma_nn_negative_at_zero(oracle):
+    """F8: Gamma_NN(0) = 4.3/(4 pi 0.2) = 1.7109 > 1 is kept (no clamp)."""
+    assert oracle.gamma_nn_r2(0.0) == pytest.approx(1.710916, rel=1e-6)
+
+
+def test_layer_b_rms_known_answer(dev):
+    """Layer B whole RMS integration (main.cu:157-286) vs quadrature: RMS of r^2 WS(2.0, 0.54) = 2.534610."""
+    from mcmc_amd import lib as L
+    cfg = L.Config()
+    L.lib.mcmc_config_default(C.byref(cfg))
+    cfg.samplesForMix = 512
+    cfg.totalRuns = 8
+    h = C.c_void_p()
+    L.check(L.lib.mcmc_create(C.byref(cfg), C.byref(h)))
+    try:
+        L.check(L.lib.mcmc_warmup(h, 2.2, cfg.samplesForMix))
+        rms = (C.c_float * 8)()
+        err = (C.c_float * 8)()
+        L.check(L.lib.mcmc_run_rms(h, rms, err))
+        for n in range(8):
+            assert err[n] > 0
+            assert abs(rms[n] - 2.534610) < max(4 * err[n], 1e-3), (n, rms[n], err[n])
+    finally:
+        L.check(L.lib.mcmc_destroy(h))
+
+
+def test_layer_b_sab_scan_and_cross_sections(dev):
+    """Layer B S_AB scan (main.cu:289-413) on He-4 + He-4 at reduced size: S_AB rises from ~0 towards 1 with b,
+    stderr > 0, and the C++ sigma integration runs on the table (f1)."""
+    from mcmc_amd import api, lib as L
+    cfg = L.Config()
+    L.lib.mcmc_config_default(C.byref(cfg))
+    cfg.totalBlocks, cfg.threadsPerBlock, cfg.samplesPerThread, cfg.totalRuns = 16, 128, 64, 4
+    cfg.ndbs, cfg.db = 40, 0.25
+    h = C.c_void_p()
+    L.check(L.lib.mcmc_create(C.byref(cfg), C.byref(h)))
+    try:
+        L.check(L.lib.mcmc_warmup(h, 2.2, 256))
+        n = cfg.ndbs
+        b, S, E = (C.c_float * n)(), (C.c_float * n)(), (C.c_float * n)()
+        pin = (C.c_double * n)()
+        L.check(L.lib.mcmc_run_sab_scan(h, b, S, E, pin, 4.3 / np.pi))
+        S = np.array(S[:])
+        assert S[0] < 0.6 and S[-1] > 0.99
+        assert np.all(np.array(E[:]) >= 0)
+        assert pin[0] > 0.8 and pin[n - 1] < 0.05
+        cs = api.CrossSections(np.array(b[:], dtype=np.float64), S.astype(np.float64), np.array(E[:], dtype=np.float64))
+        assert 200 < cs["rxn"][0] < 2000
+    finally:
+        L.check(L.lib.mcmc_destroy(h))
