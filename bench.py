@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--sweeps", type=int, default=256, help="MH sweeps per step (launch)")
     ap.add_argument("--step-size", type=float, default=2.48,
                     help="proposal width (2.48 = max-efficiency width of stepsize/results/r2WS_2.0_0.54.png)")
-    ap.add_argument("--rule", default="recip", choices=["recip", "nodiv", "log"])
+    ap.add_argument("--rule", default="recip", choices=["recip", "nodiv", "log", "cross"])
     ap.add_argument("--math", default="fast", choices=["fast", "precise"])
     ap.add_argument("--lags", type=int, default=0, help="lag products inside the timed kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,7 +91,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from mcmc_amd import api, lib as L
-    rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "log": L.ACCEPT_LOG}[args.rule]
+    rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "log": L.ACCEPT_LOG, "cross": L.ACCEPT_CROSS}[args.rule]
     math = L.MATH_FAST if args.math == "fast" else L.MATH_PRECISE
     target = api.make_target(L.TARGET_R2WS, 2.0, 0.54)   # PDF(), metropolis.hpp:19-23 / main.cu:14-19
     eng = api.ChainEngine(args.chains, args.coords, target, args.step_size, precision=32, accept_rule=rule,

@@ -57,7 +57,9 @@ typedef enum {
     MCMC_ACCEPT_RECIP = 0,        /* p' * (1/p) >= U, U in (0,1]; Metropolis.cuh:47-50 (GPU rule)       */
     MCMC_ACCEPT_SHORTCIRCUIT = 1, /* p' > p || U < p'/p, U in [0,1); metropolis.hpp:41 (CPU rule, FP64) */
     MCMC_ACCEPT_NODIV = 2,        /* p' >= U * p  (same rule, no reciprocal; not bit-identical at ties) */
-    MCMC_ACCEPT_LOG = 3           /* log U <= log p' - log p (log-space)                                 */
+    MCMC_ACCEPT_LOG = 3,          /* log U <= log p' - log p (log-space)                                 */
+    MCMC_ACCEPT_CROSS = 4         /* p' >= U p with p kept as a quotient n/d and the test cross-multiplied
+                                     (n' d >= U n d'): the same decision with no reciprocal; FAST math only */
 } mcmc_accept_rule;
 
 typedef enum {

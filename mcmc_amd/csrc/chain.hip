@@ -80,8 +80,8 @@ extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
     }
     if (rc != MCMC_OK) return rc;
     MCMC_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(chain_finalize_kernel, dim3(a->n_coords), dim3(256), 0, s, (const double *)a->workspace,
-                       a->stats, (int)MCMC_STATS_LEN(a->n_lags), (int)grid.x);
+    hipLaunchKernelGGL(chain_finalize_kernel, dim3(MCMC_STATS_LEN(a->n_lags), a->n_coords), dim3(256), 0, s,
+                       (const double *)a->workspace, a->stats, (int)MCMC_STATS_LEN(a->n_lags), (int)grid.x);
     MCMC_HIP_CHECK(hipGetLastError());
     return MCMC_OK;
 }

@@ -40,9 +40,10 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     return v;
 }
 
-// Real = float : Metropolis.cuh:40-52 arithmetic (rules RECIP / NODIV / LOG)
+// Real = float : Metropolis.cuh:40-52 arithmetic (rules RECIP / NODIV / LOG / CROSS)
 // Real = double: metropolis.hpp:35-47 arithmetic (rule SHORTCIRCUIT)
-template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ>
+// STORE: sample / accept-flag write-back requested (keeps the address arithmetic out of the hot loop otherwise)
+template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, bool STORE>
 __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
 {
     constexpr int NL = NLAG > 0 ? NLAG : 1;
@@ -57,8 +58,12 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
     for (int i = tid; i < CHAIN_WAVES * (3 + 3 * NL); i += CHAIN_BLOCK) (&sred[0][0])[i] = 0.0;
     __syncthreads();
 
+    // Philox draws in FAST math: the proposal width is folded into the Box-Muller radius
+    constexpr bool PRESCALED = !INJ && sizeof(Real) == 4 && MATH == MCMC_MATH_FAST;
     const Target<Real> tg = make_target<Real>(p.target);
     const Real step = (Real)p.step;
+    const float scale2 = -1.3862943611198906f * (float)p.step * (float)p.step;
+    (void)scale2;
     const Real center = (Real)p.center;
     const uint64_t t_begin = p.step_offset;
     const uint64_t t_end = p.step_offset + p.n_steps;
@@ -72,8 +77,9 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
         Real *state = (Real *)p.state + (uint64_t)coord * nc + ch;
 
         Real x = *state;
-        Real aux; // float: 1/p | p | log p ; double: p(x)
-        if constexpr (sizeof(Real) == 4) aux = mh_aux_init<KIND, RULE, MATH>(tg, x);
+        Real aux;          // float: 1/p | p | log p | d or g (CROSS); double: p(x)
+        float aux2 = 0.0f; // CROSS: n
+        if constexpr (sizeof(Real) == 4) mh_aux_init<KIND, RULE, MATH>(tg, x, aux, aux2);
         else aux = pdf_precise<KIND>(tg, x);
 
         Real hist[NL];
@@ -91,21 +97,26 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
 
         double S1 = 0.0, S2 = 0.0;
         float s1 = 0.0f, s2 = 0.0f;
-        uint32_t nacc = 0;
+        // accepted proposals are counted per wave on the scalar unit (ballot + s_bcnt1): no VALU slot
+        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+        uint64_t wacc = 0;
         uint64_t cursor = 0; // injected uniforms consumed (rule SHORTCIRCUIT)
         (void)cursor;
 
         // One sweep of this chain: global step t.
         auto one_step = [&](uint64_t t, Real normal, Real uniform) {
-            const uint64_t i = t - t_begin; // step within this launch
-            const uint64_t slot = (i * p.n_coords + coord) * nc + ch;
+            uint64_t slot = 0;
+            if constexpr (INJ || STORE) slot = ((t - t_begin) * p.n_coords + coord) * nc + ch;
             if constexpr (INJ) {
                 normal = ((const Real *)p.inj_normals)[slot];
                 if constexpr (RULE != MCMC_ACCEPT_SHORTCIRCUIT) uniform = ((const Real *)p.inj_uniforms)[slot];
             }
             bool take;
-            if constexpr (sizeof(Real) == 4) {
-                take = mh_step<KIND, RULE, MATH>(tg, x, aux, step, normal, uniform);
+            if constexpr (PRESCALED) {
+                take = mh_step_dz<KIND, RULE, MATH>(tg, x, aux, aux2, normal, uniform); // `normal` is step * z
+            } else if constexpr (sizeof(Real) == 4) {
+                // Metropolis.cuh:43: mul + add, two roundings
+                take = mh_step_dz<KIND, RULE, MATH>(tg, x, aux, aux2, step * normal, uniform);
             } else {
                 // metropolis.hpp:36-44
                 const Real proposed = x + step * normal;
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
                     aux = pp;
                 }
             }
-            nacc += take ? 1u : 0u;
+            wacc += (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take) & vmask);
             const Real y = x - center;
             s1 += (float)y;
             s2 = __builtin_fmaf((float)y, (float)y, s2);
@@ -134,42 +145,76 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
                 for (int k = NL - 1; k > 0; --k) hist[k] = hist[k - 1];
                 hist[0] = y;
             }
-            if (p.samples != nullptr && valid) ((Real *)p.samples)[slot] = x;
-            if (p.accept_bits != nullptr && valid) p.accept_bits[slot] = take ? 1 : 0;
+            if constexpr (STORE) {
+                if (p.samples != nullptr && valid) ((Real *)p.samples)[slot] = x;
+                if (p.accept_bits != nullptr && valid) p.accept_bits[slot] = take ? 1 : 0;
+            }
         };
 
-        auto run_steps = [&](uint64_t ta, uint64_t tb) {
-            if (ta >= tb) return;
-            for (uint64_t blk = ta >> 1; blk <= ((tb - 1) >> 1); ++blk) {
-                Real z0 = 0, z1 = 0, u0 = 0, u1 = 0;
-                if constexpr (!INJ) {
-                    const u32x4 r = draw_block(p.seed, gid, coord, blk, 0u);
-                    if constexpr (sizeof(Real) == 4) {
-                        float a, b;
-                        box_muller<MATH>(r.x, r.y, a, b);
-                        z0 = a;
-                        z1 = b;
-                        u0 = u01(r.z);
-                        u1 = u01(r.w);
-                    } else {
-                        double a, b;
-                        box_muller_f64(r.x, r.y, a, b);
-                        z0 = a;
-                        z1 = b;
-                        u0 = (double)r.z * 2.3283064365386963e-10;
-                        u1 = (double)r.w * 2.3283064365386963e-10;
-                    }
-                }
-                const uint64_t te = blk << 1;
-                if (te >= ta && te < tb) one_step(te, z0, u0);
-                if (te + 1 >= ta && te + 1 < tb) one_step(te + 1, z1, u1);
-                if ((blk & 63u) == 63u) {
-                    S1 += (double)s1;
-                    S2 += (double)s2;
-                    s1 = 0.0f;
-                    s2 = 0.0f;
+        // The draws of steps 2*blk (z0, u0) and 2*blk + 1 (z1, u1): one Philox block.
+        auto draw_pair = [&](uint64_t blk, Real &z0, Real &z1, Real &u0, Real &u1) {
+            z0 = z1 = u0 = u1 = (Real)0;
+            if constexpr (!INJ) {
+                const u32x4 r = draw_block(p.seed, gid, coord, blk, 0u);
+                if constexpr (PRESCALED) {
+                    float a, b;
+                    box_muller_scaled(r.x, r.y, scale2, a, b);
+                    z0 = a;
+                    z1 = b;
+                    u0 = u01(r.z);
+                    u1 = u01(r.w);
+                } else if constexpr (sizeof(Real) == 4) {
+                    float a, b;
+                    box_muller<MATH>(r.x, r.y, a, b);
+                    z0 = a;
+                    z1 = b;
+                    u0 = u01(r.z);
+                    u1 = u01(r.w);
+                } else {
+                    double a, b;
+                    box_muller_f64(r.x, r.y, a, b);
+                    z0 = a;
+                    z1 = b;
+                    u0 = (double)r.z * 2.3283064365386963e-10;
+                    u1 = (double)r.w * 2.3283064365386963e-10;
                 }
             }
+        };
+
+        auto flush = [&]() {
+            S1 += (double)s1;
+            S2 += (double)s2;
+            s1 = 0.0f;
+            s2 = 0.0f;
+        };
+
+        // Steps [ta, tb): an odd first step and an even last step are the halves of a Philox
+        // block; everything between runs whole blocks with no per-step range test.
+        auto run_steps = [&](uint64_t ta, uint64_t tb) {
+            if (ta >= tb) return;
+            Real z0, z1, u0, u1;
+            uint64_t blk = ta >> 1;
+            if (ta & 1) {
+                draw_pair(blk, z0, z1, u0, u1);
+                one_step(ta, z1, u1);
+                ++blk;
+            }
+            const uint64_t full_end = tb >> 1;
+            while (blk < full_end) {
+                uint64_t stop = (blk | 63u) + 1; // the float partial sums are folded into FP64 every <= 128 steps
+                if (stop > full_end) stop = full_end;
+                for (; blk < stop; ++blk) {
+                    draw_pair(blk, z0, z1, u0, u1);
+                    one_step(blk << 1, z0, u0);
+                    one_step((blk << 1) + 1, z1, u1);
+                }
+                flush();
+            }
+            if (tb & 1) {
+                draw_pair(blk, z0, z1, u0, u1);
+                one_step(tb - 1, z0, u0);
+            }
+            flush();
         };
 
         // Phase 1: the first NLAG steps of a window, after which the ring holds
@@ -190,8 +235,6 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
             }
         }
         run_steps(t_mid, t_end);
-        S1 += (double)s1;
-        S2 += (double)s2;
 
         // clamped (invalid) lanes replayed chain 0 on a possibly stale read: they never store
         if (valid) *state = x;
@@ -205,11 +248,10 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
         // wave reductions -> per-wave LDS accumulators (only lane 0 of a wave touches its row)
         const double r1 = wave_sum(valid ? S1 : 0.0);
         const double r2 = wave_sum(valid ? S2 : 0.0);
-        const double r3 = wave_sum(valid ? (double)nacc : 0.0);
         if (lane == 0) {
             sred[wave][0] += r1;
             sred[wave][1] += r2;
-            sred[wave][2] += r3;
+            sred[wave][2] += (double)wacc;
         }
         if constexpr (NLAG > 0) {
 #pragma unroll
@@ -235,21 +277,32 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
     }
 }
 
-// Fixed-order sum of the block partials: grid = n_coords, one thread per entry.
-static __global__ void chain_finalize_kernel(const double *partials, double *stats, int len, int nblocks)
+// Fixed-order sum of the block partials: grid = (len, n_coords); thread t adds partials
+// t, t+256, ... in order, then a fixed LDS tree -- the result does not depend on timing.
+static __global__ __launch_bounds__(256) void chain_finalize_kernel(const double *partials, double *stats, int len,
+                                                                  int nblocks)
 {
-    const int coord = blockIdx.x;
-    for (int i = threadIdx.x; i < len; i += blockDim.x) {
-        double tot = 0.0;
-        for (int b = 0; b < nblocks; ++b) tot += partials[((uint64_t)coord * nblocks + b) * len + i];
-        stats[(uint64_t)coord * len + i] = tot;
+    __shared__ double sh[256];
+    const int i = blockIdx.x;
+    const int coord = blockIdx.y;
+    double tot = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) tot += partials[((uint64_t)coord * nblocks + b) * len + i];
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) stats[(uint64_t)coord * len + i] = sh[0];
 }
 
 template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ>
 void launch_chain(const ChainParams &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+    if (p.samples != nullptr || p.accept_bits != nullptr)
+        hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, true>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+    else
+        hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, false>), grid, dim3(CHAIN_BLOCK), 0, s, p);
 }
 
 } // namespace mcmc

@@ -53,11 +53,12 @@ int pick_rule(const mcmc_chain_args *a, const ChainParams &p, dim3 grid, hipStre
     switch (a->accept_rule) {
     case MCMC_ACCEPT_RECIP: pick_lag_inj<float, KIND, MCMC_ACCEPT_RECIP, MCMC_MATH_FAST>(p, grid, s, inj); break;
     case MCMC_ACCEPT_NODIV: pick_lag_inj<float, KIND, MCMC_ACCEPT_NODIV, MCMC_MATH_FAST>(p, grid, s, inj); break;
+    case MCMC_ACCEPT_CROSS: pick_lag_inj<float, KIND, MCMC_ACCEPT_CROSS, MCMC_MATH_FAST>(p, grid, s, inj); break;
     case MCMC_ACCEPT_LOG:
         if (inj) return set_error(MCMC_EINVAL, "injected draws are not implemented for MCMC_ACCEPT_LOG");
         pick_lag<float, KIND, MCMC_ACCEPT_LOG, MCMC_MATH_FAST>(p, grid, s);
         break;
-    default: return set_error(MCMC_EINVAL, "32-bit accept_rule must be RECIP, NODIV or LOG");
+    default: return set_error(MCMC_EINVAL, "32-bit accept_rule must be RECIP, NODIV, LOG or CROSS");
     }
     return MCMC_OK;
 }

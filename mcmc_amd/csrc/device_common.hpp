@@ -79,6 +79,16 @@ __device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float &z_ev
     }
 }
 
+// FAST path with the proposal width folded into the radius: returns step * z for both normals
+// (scale2 = -2 ln2 * step^2), one multiply less per proposal than z followed by step * z.
+__device__ __forceinline__ void box_muller_scaled(uint32_t r0, uint32_t r1, float scale2, float &dz_even, float &dz_odd)
+{
+    const float u1 = u01(r0), u2 = u01(r1);
+    const float rad = __builtin_amdgcn_sqrtf(scale2 * __builtin_amdgcn_logf(u1));
+    dz_even = rad * __builtin_amdgcn_cosf(u2);
+    dz_odd = rad * __builtin_amdgcn_sinf(u2);
+}
+
 __device__ __forceinline__ void box_muller_f64(uint32_t r0, uint32_t r1, double &z_even, double &z_odd)
 {
     const double u1 = ((double)r0 + 0.5) * 2.3283064365386963e-10;
@@ -149,12 +159,15 @@ __device__ __forceinline__ float pdf_fast(const Target<float> &t, float r)
     if constexpr (KIND == MCMC_TARGET_WS) {
         p = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(r, t.k1, t.k0)));
     } else if constexpr (KIND == MCMC_TARGET_R2WS) {
-        p = (r * r) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(r, t.k1, t.k0)));
+        // r < 0 -> 0 through the r^2 factor: one v_max instead of compare + select
+        const float rp = __builtin_fmaxf(r, 0.0f);
+        return (rp * rp) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(r, t.k1, t.k0)));
     } else if constexpr (KIND == MCMC_TARGET_GAUSS) {
         p = __builtin_amdgcn_exp2f(r * r * t.k1);
     } else {
-        const float r2 = r * r;
-        p = r2 * __builtin_amdgcn_exp2f(r2 * t.k1);
+        const float rp = __builtin_fmaxf(r, 0.0f);
+        const float r2 = rp * rp;
+        return r2 * __builtin_amdgcn_exp2f(r2 * t.k1);
     }
     return r < 0.0f ? 0.0f : p;
 }
@@ -186,29 +199,59 @@ __device__ __forceinline__ float pdf_eval(const Target<float> &t, float r)
 }
 
 // ---------------------------------------------------------------------
-// One MH proposal in FP32 (a5, Metropolis.cuh:40-52).  `aux` is the cached
-// per-chain quantity of the rule: 1/p (RECIP), p (NODIV) or log p (LOG).
+// One MH proposal in FP32 (a5, Metropolis.cuh:40-52).  `aux` (and `aux2`) are
+// the cached per-chain quantities of the rule:
+//   RECIP : aux = 1/p                       (the reference's cached reciprocal)
+//   NODIV : aux = p
+//   LOG   : aux = log p
+//   CROSS : the density is kept as a quotient and the test p' >= U p is cross-multiplied, so no
+//           reciprocal is evaluated at all:
+//             WS      p = 1/d        aux = d = 1 + e^((r-c)/a)         d >= U d'
+//             R2WS    p = n/d        aux = d, aux2 = n = r^2           n' d >= (U n) d'
+//             GAUSS   p = 2^g        aux = g = -r^2 log2e/(2v)         2^(g'-g) >= U
+//             R2GAUSS p = n 2^g      aux = g, aux2 = n = r^2           n' 2^(g'-g) >= U n
 template <int KIND, int RULE, int MATH>
-__device__ __forceinline__ float mh_aux_init(const Target<float> &t, float x)
+__device__ __forceinline__ void mh_aux_init(const Target<float> &t, float x, float &aux, float &aux2)
 {
+    aux2 = 0.0f;
     if constexpr (RULE == MCMC_ACCEPT_RECIP) {
         const float p = pdf_eval<KIND, MATH>(t, x);
-        if constexpr (MATH == MCMC_MATH_FAST) return __builtin_amdgcn_rcpf(p);
-        else return 1.f / p; // Metropolis.cuh:64
+        if constexpr (MATH == MCMC_MATH_FAST) aux = __builtin_amdgcn_rcpf(p);
+        else aux = 1.f / p; // Metropolis.cuh:64
     } else if constexpr (RULE == MCMC_ACCEPT_NODIV) {
-        return pdf_eval<KIND, MATH>(t, x);
+        aux = pdf_eval<KIND, MATH>(t, x);
+    } else if constexpr (RULE == MCMC_ACCEPT_LOG) {
+        aux = logpdf_fast<KIND>(t, x);
     } else {
-        return logpdf_fast<KIND>(t, x);
+        const float inf = __builtin_inff();
+        const float rp = __builtin_fmaxf(x, 0.0f);
+        if constexpr (KIND == MCMC_TARGET_WS || KIND == MCMC_TARGET_R2WS) {
+            const float d = 1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(x, t.k1, t.k0));
+            aux = (KIND == MCMC_TARGET_WS && x < 0.0f) ? inf : d;
+            aux2 = rp * rp;
+        } else {
+            const float g = x * x * t.k1;
+            aux = (KIND == MCMC_TARGET_GAUSS && x < 0.0f) ? -inf : g;
+            aux2 = rp * rp;
+        }
     }
 }
 
 template <int KIND, int RULE, int MATH>
-__device__ __forceinline__ bool mh_step(const Target<float> &t, float &x, float &aux, float step, float normal,
-                                        float uniform)
+__device__ __forceinline__ float mh_aux_init(const Target<float> &t, float x)
 {
-    // Metropolis.cuh:43.  Deliberately mul + add (two roundings) in every mode: with a fused
-    // multiply-add the positions drift from the reference arithmetic by an ulp per accepted step.
-    const float next = x + step * normal;
+    static_assert(RULE != MCMC_ACCEPT_CROSS, "the cross-multiplied rule carries two cached values");
+    float a, b;
+    mh_aux_init<KIND, RULE, MATH>(t, x, a, b);
+    return a;
+}
+
+// dz = proposal displacement (step * normal).
+template <int KIND, int RULE, int MATH>
+__device__ __forceinline__ bool mh_step_dz(const Target<float> &t, float &x, float &aux, float &aux2, float dz,
+                                           float uniform)
+{
+    const float next = x + dz;
     bool take;
     if constexpr (RULE == MCMC_ACCEPT_RECIP) {
         const float pn = pdf_eval<KIND, MATH>(t, next);
@@ -223,14 +266,58 @@ __device__ __forceinline__ bool mh_step(const Target<float> &t, float &x, float 
         // p' == 0 with p == 0 can only happen for a bad start; never move onto p' == 0
         take = take && (pn > 0.0f);
         aux = take ? pn : aux;
-    } else {
+    } else if constexpr (RULE == MCMC_ACCEPT_LOG) {
         const float lpn = logpdf_fast<KIND>(t, next);
         const float lu = 0.6931471805599453f * __builtin_amdgcn_logf(uniform);
         take = lu <= lpn - aux;
         aux = take ? lpn : aux;
+    } else {
+        const float inf = __builtin_inff();
+        if constexpr (KIND == MCMC_TARGET_WS) {
+            float dn = 1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(next, t.k1, t.k0));
+            dn = next < 0.0f ? inf : dn;       // p' = 0: inf on the right-hand side rejects
+            take = aux >= uniform * dn;
+            aux = take ? dn : aux;
+        } else if constexpr (KIND == MCMC_TARGET_R2WS) {
+            const float dn = 1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(next, t.k1, t.k0));
+            const float rp = __builtin_fmaxf(next, 0.0f); // r < 0 -> n' = 0 -> 0 >= positive fails
+            const float nn = rp * rp;
+            take = nn * aux >= (uniform * aux2) * dn;
+            aux = take ? dn : aux;
+            aux2 = take ? nn : aux2;
+        } else if constexpr (KIND == MCMC_TARGET_GAUSS) {
+            float gn = next * next * t.k1;
+            gn = next < 0.0f ? -inf : gn;
+            take = __builtin_amdgcn_exp2f(gn - aux) >= uniform;
+            aux = take ? gn : aux;
+        } else {
+            const float rp = __builtin_fmaxf(next, 0.0f);
+            const float nn = rp * rp;
+            const float gn = nn * t.k1;
+            take = nn * __builtin_amdgcn_exp2f(gn - aux) >= uniform * aux2;
+            aux = take ? gn : aux;
+            aux2 = take ? nn : aux2;
+        }
     }
     x = take ? next : x;
     return take;
+}
+
+template <int KIND, int RULE, int MATH>
+__device__ __forceinline__ bool mh_step_dz(const Target<float> &t, float &x, float &aux, float dz, float uniform)
+{
+    static_assert(RULE != MCMC_ACCEPT_CROSS, "the cross-multiplied rule carries two cached values");
+    float unused = 0.0f;
+    return mh_step_dz<KIND, RULE, MATH>(t, x, aux, unused, dz, uniform);
+}
+
+template <int KIND, int RULE, int MATH>
+__device__ __forceinline__ bool mh_step(const Target<float> &t, float &x, float &aux, float step, float normal,
+                                        float uniform)
+{
+    // Metropolis.cuh:43.  Deliberately mul + add (two roundings) in every mode: with a fused
+    // multiply-add the positions drift from the reference arithmetic by an ulp per accepted step.
+    return mh_step_dz<KIND, RULE, MATH>(t, x, aux, step * normal, uniform);
 }
 
 // ---------------------------------------------------------------------
@@ -280,6 +367,16 @@ __device__ __forceinline__ float group_prod(float v)
     if constexpr (G >= 32) v *= __shfl_xor(v, 16, 64);
     if constexpr (G >= 64) v *= __shfl_xor(v, 32, 64);
     return v;
+}
+
+// c + (h ? 1 : 0) as ONE VALU op: the compare result stays a lane mask in SGPRs and enters
+// v_addc_co_u32 as the carry (hipcc otherwise materialises 0/1 with v_cndmask and adds).
+__device__ __forceinline__ uint32_t count_if(uint32_t c, bool h)
+{
+    const uint64_t m = __builtin_amdgcn_ballot_w64(h);
+    uint32_t r;
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(r) : "v"(c), "s"(m) : "vcc");
+    return r;
 }
 
 template <int G>

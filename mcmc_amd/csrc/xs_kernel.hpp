@@ -27,9 +27,10 @@ struct XsParams {
     float b;               // impact parameter
     float G0;              // sigmaNN / (4 PI beta), reference float arithmetic
     float twoBeta;         // 2.f * beta
-    float negk2;           // -log2(e) / (2 beta)
-    float dmax2;
-    int do_hits;
+    float b_stored;        // impact parameter in the units of the stored transverse positions
+    float pos_scale;       // FAST: sqrt(log2(e) / (2 beta)), so that Gamma = G0 * 2^(-d'^2); PRECISE: 1
+    float hit_d2;          // black-disk dmax^2 in the same units
+    uint32_t ga_log2;      // the G lanes of an event form a (1 << ga_log2) x (G >> ga_log2) grid over A x B
     const mcmc_target *targets;
     float *prevSample;
     const float *injected;
@@ -180,60 +181,76 @@ __device__ __forceinline__ float2 transverse(float r, float u0, float u1)
     return o;
 }
 
-// One A x B sweep for this lane's B nucleons j = j0 + lg + q*G, q < JB.
-template <int G, int JB, int MATH>
-__device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, uint32_t j0, int lg, float &prod,
-                                          uint32_t &ncoll, uint32_t &npartA_marks, uint32_t &partB, uint32_t *partA_lds,
-                                          int e_local)
+// The A x B pair tile of one lane.  The G lanes of an event form a GA x GB grid: lane (la, lb)
+// owns the A nucleons i = la + GA*k (read from LDS, one ds_read_b64 per JC pairs, prefetched one
+// iteration ahead) and keeps JC of its B nucleons j = lb + GB*(q0+q) in registers.  In FAST math
+// the stored positions are pre-multiplied by sqrt(log2(e)/(2 beta)), so a pair costs
+// 2 sub + mul + fma + v_exp_f32 + fma + mul.
+template <int JC, int MATH, bool PROD, bool HITS>
+__device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, uint32_t *partE, uint32_t la, uint32_t lb,
+                                          uint32_t GA, uint32_t GB, uint32_t q0, float &prod, uint32_t &ncoll)
 {
-    float bx[JB], by[JB], pr[JB];
-    uint32_t hb[JB];
+    float bx[JC], by[JC], pr[JC];
+    uint32_t cq[JC]; // HITS: collisions of B nucleon q (per-q counters double as the participant flags)
 #pragma unroll
-    for (int q = 0; q < JB; ++q) {
-        const uint32_t j = j0 + lg + q * G;
+    for (int q = 0; q < JC; ++q) {
+        const uint32_t j = lb + (q0 + q) * GB;
         const bool ok = j < p.nB;
         const float2 v = trE[p.nA + (ok ? j : 0)];
         bx[q] = ok ? v.x : 1.0e30f; // d^2 = inf -> Gamma = 0 -> factor exactly 1, never a hit
         by[q] = ok ? v.y : 0.0f;
         pr[q] = 1.0f;
-        hb[q] = 0;
+        cq[q] = 0u;
     }
-    for (uint32_t i = 0; i < p.nA; ++i) {
-        const float2 a = trE[i]; // same address for the whole group: LDS broadcast
-        uint32_t hit_i = 0;
+    uint32_t i = la;
+    if (i < p.nA) {
+        float2 a = trE[i];
+        for (;;) {
+            const uint32_t in = i + GA;
+            const bool more = in < p.nA;
+            const float2 an = trE[more ? in : i];
+            float dmin = __builtin_inff(); // HITS: nearest of this lane's B nucleons to A nucleon i
 #pragma unroll
-        for (int q = 0; q < JB; ++q) {
-            const float dx = a.x - bx[q]; // a.x already holds impactParameter + ux (IntegrateSAB.cuh:75)
-            const float dy = a.y - by[q];
-            float f, d2;
-            if constexpr (MATH == MCMC_MATH_FAST) {
-                d2 = __builtin_fmaf(dy, dy, dx * dx);
-                f = __builtin_fmaf(-p.G0, __builtin_amdgcn_exp2f(d2 * p.negk2), 1.0f);
-            } else {
-                d2 = dx * dx + dy * dy;
-                f = 1 - p.G0 * expf(-d2 / p.twoBeta); // IntegrateSAB.cuh:12,75
+            for (int q = 0; q < JC; ++q) {
+                const float dx = a.x - bx[q]; // a.x already holds impactParameter + ux (IntegrateSAB.cuh:75)
+                const float dy = a.y - by[q];
+                float d2;
+                if constexpr (MATH == MCMC_MATH_FAST) {
+                    d2 = __builtin_fmaf(dy, dy, dx * dx);
+                    if constexpr (PROD) pr[q] *= __builtin_fmaf(-p.G0, __builtin_amdgcn_exp2f(-d2), 1.0f);
+                } else {
+                    d2 = dx * dx + dy * dy;
+                    if constexpr (PROD) pr[q] *= 1 - p.G0 * expf(-d2 / p.twoBeta); // IntegrateSAB.cuh:12,75
+                }
+                if constexpr (HITS) {
+                    cq[q] = count_if(cq[q], d2 < p.hit_d2);
+                    dmin = __builtin_fminf(dmin, d2);
+                }
             }
-            pr[q] *= f;
-            if (p.do_hits) {
-                const uint32_t h = d2 < p.dmax2 ? 1u : 0u;
-                ncoll += h;
-                hb[q] |= h;
-                hit_i |= h;
+            if constexpr (HITS) {
+                if (dmin < p.hit_d2) partE[i] = 1u; // benign race: every writer stores 1
             }
+            if (!more) break;
+            a = an;
+            i = in;
         }
-        if (p.do_hits && hit_i) partA_lds[e_local * p.nA + i] = 1u; // benign race: every writer stores 1
     }
 #pragma unroll
-    for (int q = 0; q < JB; ++q) {
-        prod *= pr[q];
-        partB += hb[q];
+    for (int q = 0; q < JC; ++q) {
+        if constexpr (PROD) prod *= pr[q];
+        if constexpr (HITS) {
+            ncoll += cq[q];
+            if (cq[q] != 0u) partE[p.nA + lb + (q0 + q) * GB] = 1u; // a padded j never collides
+        }
     }
-    (void)npartA_marks;
 }
 
-template <int G, int KIND, int RULE, int MATH, bool INJ>
+// MODE bit 0: the S_AB product; bit 1: black-disk hit counters.
+template <int G, int KIND, int RULE, int MATH, bool INJ, int MODE>
 __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
 {
+    constexpr bool PROD = (MODE & 1) != 0;
+    constexpr bool HITS = (MODE & 2) != 0;
     constexpr int EPB = XS_BLOCK / G; // events per block
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nN = p.nA + p.nB;
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     //   float2  st [EPB][nN]   (x, aux)
     //   float2  trA[EPB][nN]   transverse positions, even sweep of the pair
     //   float2  trB[EPB][nN]   odd sweep
-    //   uint32  partA[EPB][nA] participant marks (hits only)
+    //   uint32  part[EPB][nN]  participant marks (HITS only)
     TgtLds *tgt = reinterpret_cast<TgtLds *>(smem);
     size_t off = ((sizeof(TgtLds) * nN + 15) / 16) * 16;
     float2 *st = reinterpret_cast<float2 *>(smem + off);
@@ -251,11 +268,13 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     off += sizeof(float2) * (size_t)EPB * nN;
     float2 *trB = reinterpret_cast<float2 *>(smem + off);
     off += sizeof(float2) * (size_t)EPB * nN;
-    uint32_t *partA = reinterpret_cast<uint32_t *>(smem + off);
+    uint32_t *part = reinterpret_cast<uint32_t *>(smem + off);
 
     const int tid = threadIdx.x;
     const int e_local = tid / G;
     const int lg = tid % G;
+    const uint32_t GA = 1u << p.ga_log2, GB = (uint32_t)G >> p.ga_log2;
+    const uint32_t la = (uint32_t)lg & (GA - 1), lb = (uint32_t)lg >> p.ga_log2;
     const uint64_t e0 = (uint64_t)blockIdx.x * EPB + e_local;
     const bool valid = e0 < p.T;
     const uint64_t e = valid ? e0 : 0;
@@ -276,44 +295,60 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     float2 *stE = st + (size_t)e_local * nN;
     float2 *trAE = trA + (size_t)e_local * nN;
     float2 *trBE = trB + (size_t)e_local * nN;
+    uint32_t *partE = part + (size_t)e_local * nN;
     for (uint32_t n = lg; n < nN; n += G) { // CopyLocalMHVars, Metropolis.cuh:61-66
         const float x = p.prevSample[(uint64_t)n * p.T + e];
         stE[n] = make_float2(x, sab_aux_init<KIND, RULE, MATH>(tgt[n], x));
+        if constexpr (HITS) partE[n] = 0u;
     }
 
     float sum = 0.0f, err = 0.0f;
     uint32_t h_coll = 0, h_inel = 0, h_part = 0;
     const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
+    const uint32_t JB = (p.nB + GB - 1) / GB;
 
     auto pair_sweep = [&](const float2 *trE) {
         float prod = 1.0f;
-        uint32_t ncoll = 0, partB = 0, dummy = 0;
-        for (uint32_t j0 = 0; j0 < p.nB;) {
-            const uint32_t rem = p.nB - j0;
-            if (rem > 2 * G) {
-                sab_pairs<G, 4, MATH>(p, trE, j0, lg, prod, ncoll, dummy, partB, partA, e_local);
-                j0 += 4 * G;
-            } else if (rem > G) {
-                sab_pairs<G, 2, MATH>(p, trE, j0, lg, prod, ncoll, dummy, partB, partA, e_local);
-                j0 += 2 * G;
+        uint32_t ncoll = 0;
+        for (uint32_t q0 = 0; q0 < JB;) {
+            const uint32_t rem = JB - q0;
+            if (rem >= 8) {
+                sab_pairs<8, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
+                q0 += 8;
+            } else if (rem >= 4) {
+                sab_pairs<4, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
+                q0 += 4;
+            } else if (rem >= 2) {
+                sab_pairs<2, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
+                q0 += 2;
             } else {
-                sab_pairs<G, 1, MATH>(p, trE, j0, lg, prod, ncoll, dummy, partB, partA, e_local);
-                j0 += G;
+                sab_pairs<1, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
+                q0 += 1;
             }
         }
-        float y = group_prod<G>(prod);
-        // Kahan, IntegrateSAB.cuh:81-85 (every lane of the group carries the same sum)
-        y -= err;
-        const float tt = sum + y;
-        err = (tt - sum) - y;
-        sum = tt;
-        if (p.do_hits) {
+        if constexpr (PROD) {
+            float y = group_prod<G>(prod);
+            // Kahan, IntegrateSAB.cuh:81-85 (every lane of the group carries the same sum)
+            y -= err;
+            const float tt = sum + y;
+            err = (tt - sum) - y;
+            sum = tt;
+        }
+        if constexpr (HITS) {
             ncoll = group_sum_u32<G>(ncoll);
-            partB = group_sum_u32<G>(partB);
             h_coll += ncoll;
             h_inel += ncoll > 0 ? 1u : 0u;
-            h_part += partB;
         }
+    };
+
+    // participants of the sweep just done: count and clear the marks
+    auto count_marks = [&]() {
+        uint32_t c = 0;
+        for (uint32_t n = lg; n < nN; n += G) {
+            c += partE[n];
+            partE[n] = 0u;
+        }
+        h_part += group_sum_u32<G>(c);
     };
 
     if (p.samples > 0) {
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                     a2 = u01(q.z);
                     a3 = u01(q.w);
                 }
-                const float shift = n < p.nA ? p.b : 0.0f;
+                const float shift = n < p.nA ? p.b_stored : 0.0f;
                 if (actA) {
                     if constexpr (INJ) {
                         const float *d = p.injected + e * p.inj_stride + (te - ta) * nN * 4;
@@ -345,7 +380,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                         a1 = d[2 * nN + 2 * n + 1];
                     }
                     sab_mh<KIND, RULE, MATH>(tl, s.x, s.y, p.stepsize, z0, u0);
-                    float2 t = transverse<MATH>(s.x, a0, a1);
+                    float2 t = transverse<MATH>(MATH == MCMC_MATH_FAST ? s.x * p.pos_scale : s.x, a0, a1);
                     if (n < p.nA) t.x = shift + t.x;
                     trAE[n] = t;
                 }
@@ -358,32 +393,23 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                         a3 = d[2 * nN + 2 * n + 1];
                     }
                     sab_mh<KIND, RULE, MATH>(tl, s.x, s.y, p.stepsize, z1, u1);
-                    float2 t = transverse<MATH>(s.x, a2, a3);
+                    float2 t = transverse<MATH>(MATH == MCMC_MATH_FAST ? s.x * p.pos_scale : s.x, a2, a3);
                     if (n < p.nA) t.x = shift + t.x;
                     trBE[n] = t;
                 }
                 stE[n] = s;
             }
-            if (p.do_hits)
-                for (uint32_t i = lg; i < p.nA; i += G) partA[e_local * p.nA + i] = 0u;
             __syncthreads();
             if (actA) pair_sweep(trAE);
-            if (p.do_hits) {
+            if constexpr (HITS) {
                 __syncthreads();
-                uint32_t c = 0;
-                for (uint32_t i = lg; i < p.nA; i += G) {
-                    c += partA[e_local * p.nA + i];
-                    partA[e_local * p.nA + i] = 0u;
-                }
-                if (actA) h_part += group_sum_u32<G>(c);
+                if (actA) count_marks();
                 __syncthreads();
             }
             if (actB) pair_sweep(trBE);
-            if (p.do_hits) {
+            if constexpr (HITS) {
                 __syncthreads();
-                uint32_t c = 0;
-                for (uint32_t i = lg; i < p.nA; i += G) c += partA[e_local * p.nA + i];
-                if (actB) h_part += group_sum_u32<G>(c);
+                if (actB) count_marks();
             }
             __syncthreads();
         }
@@ -392,8 +418,8 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     for (uint32_t n = lg; n < nN; n += G)
         if (valid) p.prevSample[(uint64_t)n * p.T + e] = stE[n].x;
     if (valid && lg == 0) {
-        p.result[e] = (sum - err) / p.samples; // IntegrateSAB.cuh:88
-        if (p.hits != nullptr) {
+        if constexpr (PROD) p.result[e] = (sum - err) / p.samples; // IntegrateSAB.cuh:88
+        if constexpr (HITS) {
             p.hits[e] = h_coll;
             p.hits[p.T + e] = h_inel;
             p.hits[2 * p.T + e] = h_part;

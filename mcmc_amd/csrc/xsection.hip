@@ -48,7 +48,7 @@ XsParams make_params(const mcmc_xs_args *a, uint32_t samples)
     const float PI = 3.141592653589f; // Common.cuh:21
     p.G0 = a->sigmaNN / (4 * PI * a->beta);
     p.twoBeta = 2.f * a->beta;
-    p.negk2 = -1.4426950408889634f / (2.0f * a->beta);
+    p.pos_scale = 1.0f;
     return p;
 }
 
@@ -85,46 +85,47 @@ int row_reduce(const T *x, uint32_t rows, uint64_t cols, double scale, double *o
     return MCMC_OK;
 }
 
-// Lanes per event: the power of two in {4,16,64} with the least padded work.
+// Lanes per event G in {4,16,64} and their GA x GB split over the A x B pair grid: the
+// combination with the least padded work that still leaves >= 2 blocks per CU.
 struct SabPlan {
     int G;
+    int ga_log2;
     size_t lds;
 };
 
-size_t sab_lds_bytes(int G, uint32_t nA, uint32_t nB)
+size_t sab_lds_bytes(int G, uint32_t nA, uint32_t nB, bool hits)
 {
     const size_t nN = (size_t)nA + nB;
     const size_t epb = XS_BLOCK / G;
-    return align_up(sizeof(TgtLds) * nN, 16) + 3 * sizeof(float2) * epb * nN + sizeof(uint32_t) * epb * nA;
+    return align_up(sizeof(TgtLds) * nN, 16) + 3 * sizeof(float2) * epb * nN + (hits ? sizeof(uint32_t) * epb * nN : 0);
 }
 
-SabPlan sab_plan(uint32_t nA, uint32_t nB)
+SabPlan sab_plan(uint32_t nA, uint32_t nB, bool hits)
 {
     const int cand[3] = {4, 16, 64};
-    SabPlan best{64, sab_lds_bytes(64, nA, nB)};
+    SabPlan best{64, 0, sab_lds_bytes(64, nA, nB, hits)};
     double best_cost = 1e300;
     for (int G : cand) {
-        const size_t lds = sab_lds_bytes(G, nA, nB);
+        const size_t lds = sab_lds_bytes(G, nA, nB, hits);
         if (lds > 64 * 1024 && G != 64) continue; // keep >= 2 blocks per CU unless there is no choice
         const double nN = (double)nA + nB;
         const double mh = (double)((uint32_t)(nN + G - 1) / G) * 160.0;
-        double jb = 0;
-        for (uint32_t j0 = 0; j0 < nB;) {
-            const uint32_t rem = nB - j0;
-            const int w = rem > 2u * G ? 4 : (rem > (uint32_t)G ? 2 : 1);
-            jb += w;
-            j0 += w * G;
-        }
-        const double cost = G * (mh + nA * (jb * 10.0 + 4.0) + 12.0 * (G > 1 ? __builtin_ctz(G) : 0));
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = SabPlan{G, lds};
+        for (int gl = 0; (1 << gl) <= G; ++gl) {
+            const uint32_t GA = 1u << gl, GB = (uint32_t)G >> gl;
+            const uint32_t ia = (nA + GA - 1) / GA, jb = (nB + GB - 1) / GB;
+            const uint32_t passes = jb / 8 + ((jb & 4) ? 1 : 0) + ((jb & 2) ? 1 : 0) + (jb & 1);
+            const double cost = G * (mh + (double)ia * jb * 10.0 + (double)passes * (ia * 3.0 + 16.0) + 12.0 * gl +
+                                     12.0 * __builtin_ctz(G));
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = SabPlan{G, gl, lds};
+            }
         }
     }
     return best;
 }
 
-template <int G, int KIND>
+template <int G, int KIND, int MODE>
 int launch_sab_g(const mcmc_xs_args *a, const XsParams &p, size_t lds, hipStream_t s)
 {
     constexpr int EPB = XS_BLOCK / G;
@@ -133,7 +134,7 @@ int launch_sab_g(const mcmc_xs_args *a, const XsParams &p, size_t lds, hipStream
     const bool inj = a->injected != nullptr;
 #define MCMC_SAB_LAUNCH(RULE, MATH, INJ)                                                                         \
     do {                                                                                                         \
-        auto k = sab_kernel<G, KIND, RULE, MATH, INJ>;                                                           \
+        auto k = sab_kernel<G, KIND, RULE, MATH, INJ, MODE>;                                                     \
         if (lds > 48 * 1024)                                                                                     \
             MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(k, grid, block, lds, s, p);                                                           \
@@ -153,11 +154,21 @@ int launch_sab_g(const mcmc_xs_args *a, const XsParams &p, size_t lds, hipStream
     return MCMC_OK;
 }
 
-template <int G>
+template <int G, int MODE>
 int launch_sab_kind(const mcmc_xs_args *a, const XsParams &p, size_t lds, bool all_r2ws, hipStream_t s)
 {
-    if (all_r2ws) return launch_sab_g<G, MCMC_TARGET_R2WS>(a, p, lds, s);
-    return launch_sab_g<G, -1>(a, p, lds, s);
+    if (all_r2ws) return launch_sab_g<G, MCMC_TARGET_R2WS, MODE>(a, p, lds, s);
+    return launch_sab_g<G, -1, MODE>(a, p, lds, s);
+}
+
+template <int MODE>
+int launch_sab_mode(const mcmc_xs_args *a, const XsParams &p, const SabPlan &plan, bool all_r2ws, hipStream_t s)
+{
+    switch (plan.G) {
+    case 4: return launch_sab_kind<4, MODE>(a, p, plan.lds, all_r2ws, s);
+    case 16: return launch_sab_kind<16, MODE>(a, p, plan.lds, all_r2ws, s);
+    default: return launch_sab_kind<64, MODE>(a, p, plan.lds, all_r2ws, s);
+    }
 }
 
 } // namespace
@@ -219,7 +230,8 @@ extern "C" int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuf
 {
     int rc = check_xs(a);
     if (rc) return rc;
-    if (!resultBuffer) return set_error(MCMC_EINVAL, "resultBuffer is null");
+    if (!resultBuffer && !hits) return set_error(MCMC_EINVAL, "resultBuffer and hits are both null: nothing to compute");
+    if (!resultBuffer && runMean) return set_error(MCMC_EINVAL, "runMean needs resultBuffer");
     if (samples == 0) return set_error(MCMC_EINVAL, "samples must be > 0");
     if (a->nNucleonsA == 0 || a->nNucleonsB == 0) return set_error(MCMC_EINVAL, "both nuclei need at least one nucleon");
     const uint32_t nN = a->nNucleonsA + a->nNucleonsB;
@@ -232,9 +244,10 @@ extern "C" int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuf
 
     XsParams p = make_params(a, samples);
     p.result = resultBuffer;
-    p.b = impactParameter;
-    p.dmax2 = dmax2;
-    p.do_hits = hits != nullptr;
+    // FAST: positions are stored in units of sqrt(2 beta / log2 e), so Gamma = G0 * 2^(-d'^2)
+    if (a->math_mode == MCMC_MATH_FAST) p.pos_scale = sqrtf(1.4426950408889634f / (2.0f * a->beta));
+    p.b_stored = impactParameter * p.pos_scale;
+    p.hit_d2 = dmax2 * p.pos_scale * p.pos_scale;
     uint32_t *hitbuf = nullptr;
     if (hits) {
         hitbuf = (uint32_t *)((char *)a->workspace + rowmean_bytes(nN < 4 ? 4 : nN));
@@ -244,13 +257,12 @@ extern "C" int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuf
     // `targets` is a device array, so the caller says whether one kind covers all nucleons.
     const bool all_r2ws = a->uniform_kind == MCMC_TARGET_R2WS;
 
-    const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB);
+    const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB, hits != nullptr);
     if (plan.lds > 160 * 1024) return set_error(MCMC_EINVAL, "nuclei too large for the LDS-resident S_AB kernel (A+B <= ~1600)");
-    switch (plan.G) {
-    case 4: rc = launch_sab_kind<4>(a, p, plan.lds, all_r2ws, s); break;
-    case 16: rc = launch_sab_kind<16>(a, p, plan.lds, all_r2ws, s); break;
-    default: rc = launch_sab_kind<64>(a, p, plan.lds, all_r2ws, s); break;
-    }
+    p.ga_log2 = (uint32_t)plan.ga_log2;
+    if (resultBuffer && hits) rc = launch_sab_mode<3>(a, p, plan, all_r2ws, s);
+    else if (resultBuffer) rc = launch_sab_mode<1>(a, p, plan, all_r2ws, s);
+    else rc = launch_sab_mode<2>(a, p, plan, all_r2ws, s);
     if (rc) return rc;
     if (runMean) {
         rc = row_reduce<float>(resultBuffer, 1, a->totalThreads, 1.0 / (double)a->totalThreads, runMean, 0, a->workspace,

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmcmc_hip.so")
 
 TARGET_WS, TARGET_R2WS, TARGET_GAUSS, TARGET_R2GAUSS = 0, 1, 2, 3
-ACCEPT_RECIP, ACCEPT_SHORTCIRCUIT, ACCEPT_NODIV, ACCEPT_LOG = 0, 1, 2, 3
+ACCEPT_RECIP, ACCEPT_SHORTCIRCUIT, ACCEPT_NODIV, ACCEPT_LOG, ACCEPT_CROSS = 0, 1, 2, 3, 4
 MATH_PRECISE, MATH_FAST = 0, 1
 MAX_LAGS = 49
 

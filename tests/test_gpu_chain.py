@@ -52,14 +52,14 @@ def test_fp64_cpu_rule_injected_matches_a1(dev, oracle, target, step):
     assert summ[0]["acceptance"] == pytest.approx(tot_acc / (n_steps * n_chains), abs=1e-12)
 
 
-@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast"])
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast", "cross_fast"])
 @pytest.mark.parametrize("target", [R2WS_REF, R2GAUSS_1, (O.WS, 2.0, 0.54), (O.GAUSS, 1.5, 0.0)])
 def test_fp32_gpu_rule_injected_matches_a5(dev, oracle, mode, target):
     """a5/a7: Metropolis.cuh:40-52 with injected draws, n_coords coordinates per
     chain (the Gibbs sweep); accept bits identical, positions to 1e-6."""
     from mcmc_amd import lib as L
     rule, math = {"recip_precise": (L.ACCEPT_RECIP, L.MATH_PRECISE), "recip_fast": (L.ACCEPT_RECIP, L.MATH_FAST),
-                  "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST)}[mode]
+                  "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "cross_fast": (L.ACCEPT_CROSS, L.MATH_FAST)}[mode]
     n_steps, n_chains, n_coords, step = 1024, 7, 3, 2.2
     rng = np.random.default_rng(99)
     normals = rng.standard_normal((n_steps, n_coords, n_chains)).astype(np.float32)
@@ -186,12 +186,13 @@ def test_split_launches_and_chain_partition_are_invariant(dev):
     np.testing.assert_allclose((t0 + t1).cpu().numpy(), sa.cpu().numpy(), rtol=1e-12, atol=1e-9)
 
 
-@pytest.mark.parametrize("mode", ["recip_fast", "nodiv_fast", "log_fast", "recip_precise"])
+@pytest.mark.parametrize("mode", ["recip_fast", "nodiv_fast", "log_fast", "cross_fast", "recip_precise"])
 def test_known_answer_r2ws_large(dev, mode):
     """Full-size property test: 2^20 chains x 3 coords; <r^2> of r^2 WS(2.0,0.54) = 6.424247."""
     from mcmc_amd import lib as L
     rule, math = {"recip_precise": (L.ACCEPT_RECIP, L.MATH_PRECISE), "recip_fast": (L.ACCEPT_RECIP, L.MATH_FAST),
-                  "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "log_fast": (L.ACCEPT_LOG, L.MATH_FAST)}[mode]
+                  "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "log_fast": (L.ACCEPT_LOG, L.MATH_FAST),
+                  "cross_fast": (L.ACCEPT_CROSS, L.MATH_FAST)}[mode]
     N, n = 1 << 20, 400
     eng = _engine(dev, n_chains=N, n_coords=3, target=R2WS_REF, step=2.2, precision=32, accept_rule=rule,
                   math_mode=math, n_lags=0, center=0.0)
