@@ -272,6 +272,10 @@ int mcmc_stepsize_run(const mcmc_target *target, int precision, int accept_rule,
                       uint64_t seed, double x0, mcmc_chain_summary *summary /* [n_coords] */,
                       double *rho /* [n_coords][n_lags] or NULL */, void *samples_host /* or NULL */);
 
+/* Isotope name ("PB-208", "208-pb") -> Z and A: NuclearZAndA, xsection/tools/MCMCMacro.py:63-83
+ * (used by IntegrationSettings.SetIsotopeA/B, :145-157: protons = Z, neutrons = A - Z). */
+int mcmc_isotope(const char *name, int *Z, int *A);
+
 const char *mcmc_last_error(void);
 const char *mcmc_version(void);
 int mcmc_device_count(void);

@@ -2,8 +2,11 @@
 // names (xsection/src/main.cu:38-82), mcmc_stepsize_run, and the host
 // statistics with the reference's arithmetic (Statistics.cuh, statistics.hpp,
 // XSectionAnalysis.py).  Built on Layer A; owns its device memory.
+#include <cctype>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "host_common.hpp"
@@ -133,6 +136,45 @@ extern "C" int mcmc_cross_sections(const double *b, const double *S, const doubl
     out[4] = 10 * 2 * pi * trapz(b, y, n);
     out[5] = 10 * trapz_unc(b, e, n);
     return MCMC_OK;
+}
+
+// ---------------------------------------------------------------------
+// Isotope names -> (Z, A): NuclearZAndA, xsection/tools/MCMCMacro.py:63-83.  Accepts
+// "PB-208" and "208-PB", any case.  (The reference's table spells californium "CT";
+// both "CF" and "CT" are accepted for Z = 98.)
+namespace {
+const char *const kElements[] = {
+    "H",  "HE", "LI", "BE", "B",  "C",  "N",  "O",  "F",  "NE", "NA", "MG", "AL", "SI", "P",  "S",  "CL", "AR", "K",  "CA",
+    "SC", "TI", "V",  "CR", "MN", "FE", "CO", "NI", "CU", "ZN", "GA", "GE", "AS", "SE", "BR", "KR", "RB", "SR", "Y",  "ZR",
+    "NB", "MO", "TC", "RU", "RH", "PD", "AG", "CD", "IN", "SN", "SB", "TE", "I",  "XE", "CS", "BA", "LA", "CE", "PR", "ND",
+    "PM", "SM", "EU", "GD", "TB", "DY", "HO", "ER", "TM", "YB", "LU", "HF", "TA", "W",  "RE", "OS", "IR", "PT", "AU", "HG",
+    "TL", "PB", "BI", "PO", "AT", "RN", "FR", "RA", "AC", "TH", "PA", "U",  "NP", "PU", "AM", "CM", "BK", "CF", "ES", "FM",
+    "MD", "NO", "LR", "RF", "DB", "SG", "BH", "HS", "MT", "DS", "RG", "CN", "NH", "FL", "MC", "LV", "TS", "OG"};
+}
+
+extern "C" int mcmc_isotope(const char *name, int *Z, int *A)
+{
+    if (!name || !Z || !A) return set_error(MCMC_EINVAL, "null pointer");
+    const char *dash = std::strchr(name, '-');
+    if (!dash || dash == name || dash[1] == 0) return set_error(MCMC_EINVAL, "isotope must look like PB-208 or 208-PB");
+    std::string left(name, dash), right(dash + 1);
+    const bool digits_first = left[0] >= '0' && left[0] <= '9';
+    std::string sym = digits_first ? right : left;
+    const std::string num = digits_first ? left : right;
+    for (char &c : sym) c = (char)std::toupper((unsigned char)c);
+    if (sym == "CT") sym = "CF";
+    char *end = nullptr;
+    const long a = std::strtol(num.c_str(), &end, 10);
+    if (*end != 0 || a <= 0) return set_error(MCMC_EINVAL, "bad mass number in isotope name");
+    for (size_t i = 0; i < sizeof(kElements) / sizeof(kElements[0]); ++i) {
+        if (sym == kElements[i]) {
+            if (a < (long)i + 1) return set_error(MCMC_EINVAL, "mass number smaller than the atomic number");
+            *Z = (int)i + 1;
+            *A = (int)a;
+            return MCMC_OK;
+        }
+    }
+    return set_error(MCMC_EINVAL, "unknown element symbol");
 }
 
 // ---------------------------------------------------------------------

@@ -1,0 +1,186 @@
+// xsection -- the Glauber integration driver of the reference
+// (xsection/src/main.cu:31-424) over the C ABI of libmcmc_hip.so.
+//
+// Same flow: allocate + InitSampleArray (main.cu:123-134) -> WarmupMetropolis
+// (:149) -> RMS integration (:157-286) -> S_AB scan over impact parameters
+// (:289-413) -> write results (:416).  The reference fixes every parameter at
+// compile time (main.cu:38-82 or a generated .mac file, MCMCMacro.py:305-368);
+// here the SAME names are run-time `name=value` arguments:
+//
+//   nNeutronA nProtonA nNeutronB nProtonB | isotopeA=PB-208 isotopeB=AU-197
+//   pdfA=r2ws:6.62:0.546  pdfB=...  (kind:p0[:p1], kinds ws r2ws gauss r2gauss; both nuclei: pdf=...)
+//   totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix
+//   b0 db ndbs seed stepsize sigmaNN beta outDir outFile integrateRMS integrateSAB
+//   blackDisk=1 (adds the hit-test inelastic probability, d < sqrt(sigmaNN/pi))  math=fast|precise
+//
+// Results: <outDir><outFile>.RMS.csv and .S_AB.csv with the reference's TTree columns
+// (IntegrationOutputHandler.cuh:83-87,109-112), and sigma_tot / sigma_el / sigma_rxn from the
+// S_AB table (xsection/tools/XSectionAnalysis.py:3-28) on stdout.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mcmc_hip.h"
+#include "output.hpp"
+
+namespace {
+
+bool parse_pdf(const std::string &v, mcmc_target &t)
+{
+    const size_t c1 = v.find(':');
+    if (c1 == std::string::npos) return false;
+    const std::string kind = v.substr(0, c1);
+    t.kind = kind == "ws" ? MCMC_TARGET_WS : kind == "r2ws" ? MCMC_TARGET_R2WS : kind == "gauss" ? MCMC_TARGET_GAUSS
+             : kind == "r2gauss" ? MCMC_TARGET_R2GAUSS : -1;
+    if (t.kind < 0) return false;
+    const size_t c2 = v.find(':', c1 + 1);
+    t.p0 = (float)std::atof(v.substr(c1 + 1, c2 == std::string::npos ? std::string::npos : c2 - c1 - 1).c_str());
+    t.p1 = c2 == std::string::npos ? 0.0f : (float)std::atof(v.substr(c2 + 1).c_str());
+    return true;
+}
+
+void die(const char *what)
+{
+    std::fprintf(stderr, "xsection: %s: %s\n", what, mcmc_last_error());
+    std::exit(1);
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    mcmc_config cfg;
+    mcmc_config_default(&cfg); // the constants of main.cu:38-82
+    std::string outDir = "./", outFile = "out"; // main.cu:73-74 ("../data/", "out.root")
+    bool integrateRMS = true, integrateSAB = true, blackDisk = false; // main.cu:81-82
+
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        const size_t eq = a.find('=');
+        if (a == "--help" || a == "-h" || eq == std::string::npos) {
+            if (eq == std::string::npos && a != "--help" && a != "-h" && argc == 2) { // main.cu:77-79: lone argument = output file
+                outFile = a;
+                continue;
+            }
+            std::puts("usage: xsection [name=value ...]   names: nNeutronA nProtonA nNeutronB nProtonB isotopeA isotopeB pdf pdfA\n"
+                      "       pdfB totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix b0 db ndbs seed stepsize\n"
+                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk math device");
+            return a == "--help" || a == "-h" ? 0 : 2;
+        }
+        const std::string k = a.substr(0, eq), v = a.substr(eq + 1);
+        const int iv = std::atoi(v.c_str());
+        const float fv = (float)std::atof(v.c_str());
+        mcmc_target t;
+        int Z, A;
+        if (k == "nNeutronA") cfg.nNeutronA = iv;
+        else if (k == "nProtonA") cfg.nProtonA = iv;
+        else if (k == "nNeutronB") cfg.nNeutronB = iv;
+        else if (k == "nProtonB") cfg.nProtonB = iv;
+        else if (k == "isotopeA" || k == "isotopeB") { // IntegrationSettings.SetIsotopeA/B, MCMCMacro.py:145-157
+            if (mcmc_isotope(v.c_str(), &Z, &A)) die(a.c_str());
+            if (k == "isotopeA") cfg.nProtonA = Z, cfg.nNeutronA = A - Z;
+            else cfg.nProtonB = Z, cfg.nNeutronB = A - Z;
+        } else if (k == "pdf" || k == "pdfA" || k == "pdfB") {
+            if (!parse_pdf(v, t)) {
+                std::fprintf(stderr, "xsection: bad density '%s' (kind:p0[:p1])\n", v.c_str());
+                return 2;
+            }
+            if (k != "pdfB") cfg.neutronA = cfg.protonA = t;
+            if (k != "pdfA") cfg.neutronB = cfg.protonB = t;
+        } else if (k == "totalBlocks") cfg.totalBlocks = iv;
+        else if (k == "threadsPerBlock") cfg.threadsPerBlock = iv;
+        else if (k == "samplesPerThread") cfg.samplesPerThread = iv;
+        else if (k == "totalRuns") cfg.totalRuns = iv;
+        else if (k == "samplesForMix") cfg.samplesForMix = iv;
+        else if (k == "b0") cfg.b0 = fv;
+        else if (k == "db") cfg.db = fv;
+        else if (k == "ndbs") cfg.ndbs = iv;
+        else if (k == "seed") cfg.seed = std::strtoull(v.c_str(), nullptr, 10);
+        else if (k == "stepsize") cfg.stepsize = fv;
+        else if (k == "sigmaNN") cfg.sigmaNN = fv;
+        else if (k == "beta") cfg.beta = fv;
+        else if (k == "device") cfg.device = iv;
+        else if (k == "math") cfg.math_mode = v == "precise" ? MCMC_MATH_PRECISE : MCMC_MATH_FAST;
+        else if (k == "outDir") outDir = v;
+        else if (k == "outFile") outFile = v;
+        else if (k == "integrateRMS") integrateRMS = iv != 0;
+        else if (k == "integrateSAB") integrateSAB = iv != 0;
+        else if (k == "blackDisk") blackDisk = iv != 0;
+        else {
+            std::fprintf(stderr, "xsection: unknown parameter '%s'\n", k.c_str());
+            return 2;
+        }
+    }
+    if (!outDir.empty() && outDir.back() != '/') outDir += '/';
+    if (mcmc_device_count() <= 0) {
+        std::fprintf(stderr, "xsection: no HIP device (%s); this build has no CPU path\n", mcmc_last_error());
+        return 3;
+    }
+
+    const int nNucleonsA = cfg.nNeutronA + cfg.nProtonA, nNucleonsB = cfg.nNeutronB + cfg.nProtonB;
+    const int nNucleons = nNucleonsA + nNucleonsB;
+    const double totalThreads = (double)cfg.totalBlocks * cfg.threadsPerBlock; // main.cu:89-92
+    const double samplesPerRun = cfg.samplesPerThread * totalThreads;
+    const double totalSamples = samplesPerRun * cfg.totalRuns;
+    std::printf("%s\nnucleus A: %d nucleons, nucleus B: %d nucleons\n", mcmc_version(), nNucleonsA, nNucleonsB);
+    std::printf("per integral: %.0f threads x %d samples x %d runs = %.0f samples (log10 %.2f); S_AB scan: %d impact "
+                "parameters, %.3g samples (log10 %.2f)\n",
+                totalThreads, cfg.samplesPerThread, cfg.totalRuns, totalSamples, std::log10(totalSamples), cfg.ndbs,
+                totalSamples * cfg.ndbs, std::log10(totalSamples * cfg.ndbs));
+
+    mcmc_handle h = nullptr;
+    if (mcmc_create(&cfg, &h)) die("mcmc_create");
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+
+    auto t0 = now();
+    if (mcmc_warmup(h, cfg.stepsize, cfg.samplesForMix)) die("mcmc_warmup"); // main.cu:149
+    std::printf("Metropolis chain warm-up (%d sweeps): %.1f ms\n", cfg.samplesForMix, ms(t0, now()));
+
+    if (integrateRMS) { // main.cu:157-286
+        std::vector<float> rms(nNucleons), err(nNucleons);
+        t0 = now();
+        if (mcmc_run_rms(h, rms.data(), err.data())) die("mcmc_run_rms");
+        const double t = ms(t0, now());
+        std::printf("RMS results (%.1f ms, %.3g proposals/s)\n", t, totalSamples * nNucleons / (t * 1e-3));
+        for (int n = 0; n < nNucleons; ++n) std::printf("Nucleon %d has RMS = %g +/- %g\n", n, rms[n], err[n]); // main.cu:264
+        if (!mcmc_host::write_rms_csv(rms, err, nNucleonsA, outDir + outFile + ".RMS.csv")) {
+            std::fprintf(stderr, "xsection: cannot write %s%s.RMS.csv\n", outDir.c_str(), outFile.c_str());
+            return 1;
+        }
+    }
+
+    if (integrateSAB) { // main.cu:289-413
+        const int n = cfg.ndbs;
+        std::vector<float> b(n), S(n), E(n);
+        std::vector<double> pin(n);
+        const float dmax2 = cfg.sigmaNN / 3.14159265358979f; // black disk: sigma_NN = pi d_max^2
+        t0 = now();
+        if (mcmc_run_sab_scan(h, b.data(), S.data(), E.data(), blackDisk ? pin.data() : nullptr, dmax2)) die("mcmc_run_sab_scan");
+        const double t = ms(t0, now());
+        std::printf("S_AB scan: %d impact parameters in %.1f ms (%.3g event samples/s, %.3g pair terms/s)\n", n, t,
+                    totalSamples * n / (t * 1e-3), totalSamples * n * nNucleonsA * nNucleonsB / (t * 1e-3));
+        if (!mcmc_host::write_sab_csv(b, S, E, blackDisk ? &pin : nullptr, outDir + outFile + ".S_AB.csv")) {
+            std::fprintf(stderr, "xsection: cannot write %s%s.S_AB.csv\n", outDir.c_str(), outFile.c_str());
+            return 1;
+        }
+        if (n >= 2) { // XSectionAnalysis.py:10-28
+            std::vector<double> bd(b.begin(), b.end()), Sd(S.begin(), S.end()), Ed(E.begin(), E.end());
+            double cs[6];
+            if (mcmc_cross_sections(bd.data(), Sd.data(), Ed.data(), n, cs)) die("mcmc_cross_sections");
+            std::printf("sigma_tot = %.3f +/- %.3f mb\nsigma_el  = %.3f +/- %.3f mb\nsigma_rxn = %.3f +/- %.3f mb\n", cs[0], cs[1],
+                        cs[2], cs[3], cs[4], cs[5]);
+            if (blackDisk) { // sigma_inel = 2 pi int b p_inel(b) db (trapezoid), x10: fm^2 -> mb
+                double s = 0;
+                for (int i = 0; i + 1 < n; ++i) s += 0.5 * (bd[i] * pin[i] + bd[i + 1] * pin[i + 1]) * (bd[i + 1] - bd[i]);
+                std::printf("sigma_inel (black disk) = %.3f mb\n", 10 * 2 * 3.14159265358979323846 * s);
+            }
+        }
+    }
+    if (mcmc_destroy(h)) die("mcmc_destroy"); // main.cu:419-422
+    return 0;
+}

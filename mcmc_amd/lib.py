@@ -76,7 +76,7 @@ EXPORTS = [
     "mcmc_Average_f64", "mcmc_Variance_f64", "mcmc_AutoCorrelation_f64", "mcmc_cross_sections",
     "mcmc_config_default", "mcmc_create", "mcmc_destroy", "mcmc_warmup", "mcmc_integrate_r2",
     "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_get_state", "mcmc_wait",
-    "mcmc_stepsize_run", "mcmc_last_error", "mcmc_version", "mcmc_device_count",
+    "mcmc_stepsize_run", "mcmc_isotope", "mcmc_last_error", "mcmc_version", "mcmc_device_count",
 ]
 
 
@@ -133,6 +133,7 @@ def _load():
     lib.mcmc_stepsize_run.argtypes = [P(Target), C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, P(ChainSummary),
                                       P(C.c_double), C.c_void_p]
+    lib.mcmc_isotope.argtypes = [C.c_char_p, P(C.c_int), P(C.c_int)]
     lib.mcmc_last_error.restype = C.c_char_p
     lib.mcmc_version.restype = C.c_char_p
     lib.mcmc_device_count.restype = C.c_int

@@ -1,0 +1,100 @@
+"""The two C++ host drivers (mcmc_amd/host/stepsize, xsection): the drop-in
+replacements of the reference's executables, driven through their command lines.
+CPU part: they exist, parse, and refuse to run without a device (no CPU path).
+GPU part: output formats of fileio.hpp / IntegrationOutputHandler.cuh and known answers."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPSIZE = os.path.join(ROOT, "mcmc_amd", "host", "stepsize")
+XSECTION = os.path.join(ROOT, "mcmc_amd", "host", "xsection")
+
+
+def test_isotope_table_matches_reference_values():
+    """mcmc_isotope == NuclearZAndA (MCMCMacro.py:78-83); expected values printed by the reference's function."""
+    from mcmc_amd import lib as L
+    expect = {"PB-208": (82, 208), "AU-197": (79, 197), "208-PB": (82, 208), "c-12": (6, 12), "HE-4": (2, 4),
+              "U-238": (92, 238), "12-C": (6, 12)}
+    for name, (z, a) in expect.items():
+        Z, A = C.c_int(), C.c_int()
+        L.check(L.lib.mcmc_isotope(name.encode(), C.byref(Z), C.byref(A)))
+        assert (Z.value, A.value) == (z, a), name
+    for bad in ("PB208", "XX-12", "PB-", "HE-1"):
+        assert L.lib.mcmc_isotope(bad.encode(), C.byref(Z), C.byref(A)) == -1
+
+
+def test_drivers_exist_and_have_no_cpu_path():
+    import torch
+    for exe in (STEPSIZE, XSECTION):
+        assert os.access(exe, os.X_OK), f"{exe} not built (make drivers)"
+        r = subprocess.run([exe, "--help"], capture_output=True, text=True)
+        assert "usage" in r.stdout
+    if not torch.cuda.is_available():
+        r = subprocess.run([STEPSIZE, "--chains", "4"], capture_output=True, text=True)
+        assert r.returncode == 3 and "no CPU path" in r.stderr
+        r = subprocess.run([XSECTION, "ndbs=2"], capture_output=True, text=True)
+        assert r.returncode == 3 and "no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_stepsize_driver_statistics_file(dev, tmp_path):
+    """BASELINE config 0 shape at reduced sweep: statistics.txt in fileio.hpp:19-43 format; acceptance falls with
+    the width and matches the reference's recorded end points (StepSizeAnalysis.ipynb: 0.9968 @0.01, 0.2280 @5.00)."""
+    r = subprocess.run([STEPSIZE, "--chains", "1024", "--iterations", "10000", "--first", "1", "--last", "500",
+                        "--stride", "499", "--outdir", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = open(tmp_path / "statistics.txt").read().splitlines()
+    assert lines[0] == "# Stepsize Acceptance " + " ".join(f"k={k}" for k in range(1, 50))
+    rows = np.array([[float(x) for x in l.split()] for l in lines[1:]])
+    assert rows.shape == (2, 51) and rows[0, 0] == 0.01 and rows[1, 0] == 5.0
+    # width 0.01: 1e4 iterations are not stationary (the walk covers ~1 fm), so only the level is comparable
+    assert 0.99 < rows[0, 1] < 0.999
+    assert rows[1, 1] == pytest.approx(0.228044, abs=3e-3)
+    # chains start at x0 = 1 (metropolis.hpp:29) and barely move at width 0.01: strongly correlated
+    assert rows[0, 2] > 0.99 and rows[1, 2] == pytest.approx(0.746, abs=0.01)
+
+
+@pytest.mark.gpu
+def test_stepsize_driver_single_chain_samples(dev, tmp_path):
+    """One chain with --samples reproduces the reference's per-width sample files (fileio.hpp:8-17)."""
+    r = subprocess.run([STEPSIZE, "--chains", "1", "--iterations", "2000", "--first", "248", "--last", "248",
+                        "--samples", "--outdir", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    s = np.loadtxt(tmp_path / "samples_248.txt")
+    assert s.shape == (2000,) and s.min() > 0 and 1.5 < s.mean() < 3.2
+
+
+@pytest.mark.gpu
+def test_xsection_driver_tables(dev, tmp_path):
+    """He-4 + He-4 (main.cu:38-41) at reduced size: RMS and S_AB tables with the TTree columns, RMS vs quadrature."""
+    r = subprocess.run([XSECTION, "totalBlocks=64", "threadsPerBlock=128", "samplesPerThread=64", "totalRuns=4",
+                        "samplesForMix=512", "ndbs=30", "db=0.3", "blackDisk=1", f"outDir={tmp_path}", "outFile=t"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    rms = np.genfromtxt(tmp_path / "t.RMS.csv", delimiter=",", names=True)
+    assert rms.dtype.names == ("Nucleus", "Nucleon", "RMS", "RMS_stderr")
+    assert list(rms["Nucleus"]) == [1, 1, 1, 1, 2, 2, 2, 2] and list(rms["Nucleon"]) == [1, 2, 3, 4] * 2
+    assert np.all(np.abs(rms["RMS"] - 2.534610) < np.maximum(5 * rms["RMS_stderr"], 2e-3))
+    sab = np.genfromtxt(tmp_path / "t.S_AB.csv", delimiter=",", names=True)
+    assert sab.dtype.names == ("b", "S_AB", "S_AB_stderr", "p_inel")
+    assert len(sab) == 30 and sab["S_AB"][0] < 0.6 and sab["S_AB"][-1] > 0.99
+    assert sab["p_inel"][0] > 0.8 and sab["p_inel"][-1] < 0.05
+    assert "sigma_rxn" in r.stdout and "sigma_inel (black disk)" in r.stdout
+
+
+@pytest.mark.gpu
+def test_xsection_driver_isotopes(dev, tmp_path):
+    """Heavy-ion path end to end: Pb-208 + Pb-208 by isotope name, literature Woods-Saxon, few events."""
+    r = subprocess.run([XSECTION, "isotopeA=PB-208", "isotopeB=PB-208", "pdf=r2ws:6.62:0.546", "sigmaNN=6.76",
+                        "totalBlocks=8", "threadsPerBlock=128", "samplesPerThread=8", "totalRuns=2", "samplesForMix=600",
+                        "integrateRMS=0", "b0=0", "db=4", "ndbs=6", "blackDisk=1", f"outDir={tmp_path}", "outFile=pb"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "nucleus A: 208 nucleons, nucleus B: 208 nucleons" in r.stdout
+    sab = np.genfromtxt(tmp_path / "pb.S_AB.csv", delimiter=",", names=True)
+    assert sab["p_inel"][0] == 1.0 and sab["p_inel"][-1] < 0.01   # b = 0 always interacts, b = 20 fm never
+    assert sab["S_AB"][0] < 1e-6 and sab["S_AB"][-1] > 0.99
