@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--sweeps", type=int, default=256, help="MH sweeps per step (launch)")
     ap.add_argument("--step-size", type=float, default=2.48,
                     help="proposal width (2.48 = max-efficiency width of stepsize/results/r2WS_2.0_0.54.png)")
-    ap.add_argument("--rule", default="recip", choices=["recip", "nodiv", "log", "cross"])
+    ap.add_argument("--rule", default="cross", choices=["recip", "nodiv", "log", "cross"],
+                    help="accept rule: cross = p' >= U p cross-multiplied (default), recip = the reference's cached-reciprocal form")
     ap.add_argument("--math", default="fast", choices=["fast", "precise"])
     ap.add_argument("--lags", type=int, default=0, help="lag products inside the timed kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,7 +91,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from mcmc_amd import api, lib as L
+    from mcmc_amd import api, dist as D, lib as L
     rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "log": L.ACCEPT_LOG, "cross": L.ACCEPT_CROSS}[args.rule]
     math = L.MATH_FAST if args.math == "fast" else L.MATH_PRECISE
     target = api.make_target(L.TARGET_R2WS, 2.0, 0.54)   # PDF(), metropolis.hpp:19-23 / main.cu:14-19
@@ -100,8 +101,7 @@ def main():
 
     def step():
         st = eng.run(args.sweeps, window_start=True)
-        if dist is not None:
-            dist.all_reduce(st)        # the one collective per batch: sufficient statistics only
+        D.allreduce_stats(st)          # the one collective per batch: sufficient statistics only (no-op for N = 1)
         return st
 
     def fence():
@@ -119,14 +119,9 @@ def main():
         evs[i][0].record()
         st = eng.run(args.sweeps, window_start=True)
         evs[i][1].record()
-        if dist is not None:
-            dist.all_reduce(st)
+        D.allreduce_stats(st)
     fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
 
     proposals_per_step = world * args.chains * args.coords * args.sweeps
@@ -136,6 +131,15 @@ def main():
     out = None
     if rank == 0:
         launch_props = args.chains * args.coords * args.sweeps
+        # HBM bytes per launch from the committed PMC passes of this same workload (tools/gpu_profile.sh;
+        # FETCH_SIZE / WRITE_SIZE in their own runs, FETCH doubled per MI355X_MICROARCH.md), else null
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_chain_kernel_v2.json")))
+            if args.chains == 1 << 24 and args.coords == 3 and args.lags == 0:
+                traffic = pm["derived"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         achieved = FLOP_PER_PROPOSAL * launch_props / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "MH proposals/sec", "value": value, "unit": "proposals/s", "n_gpus": world,
@@ -147,27 +151,38 @@ def main():
                        "accept_rule": args.rule, "math": args.math, "lags_in_kernel": args.lags,
                        "rng": "philox4x32-10", "parallelism": f"chains sharded over {world} GPU(s)"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / VALU_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "mcmc::chain_kernel", "kernel_ms": kernel_ms,
                          "flop_per_proposal": FLOP_PER_PROPOSAL, "proposals_per_launch": launch_props,
-                         "note": "FP32 VALU-bound (state in registers, no per-step HBM traffic); algorithmic flop "
-                                 "count excludes Philox integer work; HBM traffic per launch = state load/store only"},
+                         "note": "FP32 VALU-issue-bound (state in registers, no per-step HBM traffic). achieved = 24 "
+                                 "algorithmic FP32 flop per proposal (SURVEY 8d) / kernel time; Philox integer work and "
+                                 "quarter-rate transcendentals are not counted as flops, so frac understates VALU "
+                                 "occupancy (PMC: the kernel issues at the VALU limit of its instruction mix, DESIGN.md "
+                                 "4.1). traffic = HBM bytes per launch from the PMC passes under profiles/"},
             "estimates": {"mean_r": summ[0]["mean"], "var_r": summ[0]["variance"],
                           "acceptance": summ[0]["acceptance"]},
         }
-    # ESS/sec: tau_int from a lag-49 window at the same width on a chain subset (not timed)
+    # ESS/sec: tau_int = 1 + 2 sum rho_k from the streaming lag-49 accumulators at the same width, on a chain
+    # subset after warm-up (outside the timed region); the same launches give the throughput of the kernel
+    # with all 49 lag products carried by every chain.
     if not args.no_ess:
-        sub = min(args.chains, 1 << 20)
-        e2 = api.ChainEngine(sub, 1, target, args.step_size, precision=32, accept_rule=rule, math_mode=math,
+        sub = min(args.chains, 1 << 22)
+        e2 = api.ChainEngine(sub, args.coords, target, args.step_size, precision=32, accept_rule=rule, math_mode=math,
                              n_lags=L.MAX_LAGS, seed=314159265, x0=1.0, chain_offset=rank * args.chains, center=2.3,
                              device=dev)
         e2.run(512, n_lags=0)
-        e2.run(2048, window_start=True, n_lags=L.MAX_LAGS)
+        e2.run(256, window_start=True, n_lags=L.MAX_LAGS)
+        torch.cuda.synchronize()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        e2.run(1024, window_start=True, n_lags=L.MAX_LAGS)
+        eb.record()
         torch.cuda.synchronize()
         tau = e2.summary()[0]["tau_int"]
         if out is not None:
             out["ess_per_sec"] = value / tau
             out["tau_int"] = tau
+            out["lag49_proposals_per_sec_per_gpu"] = sub * args.coords * 1024 / (ea.elapsed_time(eb) * 1e-3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
     elif rank == 0:

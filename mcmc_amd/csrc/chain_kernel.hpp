@@ -5,12 +5,22 @@
 // (fixed-order partials).  No per-step HBM traffic unless sample write-back
 // or injected draws are requested.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "device_common.hpp"
 
 namespace mcmc {
 
 constexpr int CHAIN_BLOCK = 256;
 constexpr int CHAIN_WAVES = CHAIN_BLOCK / 64;
+constexpr int LAGPAD = 4; // steps per lag-window group (even)
+
+template <typename F, int... Is>
+__device__ __forceinline__ void expand_sequence(F &&f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
 
 struct ChainParams {
     uint64_t n_chains;
@@ -44,7 +54,7 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 // Real = double: metropolis.hpp:35-47 arithmetic (rule SHORTCIRCUIT)
 // STORE: sample / accept-flag write-back requested (keeps the address arithmetic out of the hot loop otherwise)
 template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, bool STORE>
-__global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
+__global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 2 : 1) void chain_kernel(const ChainParams p)
 {
     constexpr int NL = NLAG > 0 ? NLAG : 1;
     __shared__ double sred[CHAIN_WAVES][3 + 3 * NL];
@@ -82,17 +92,21 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
         if constexpr (sizeof(Real) == 4) mh_aux_init<KIND, RULE, MATH>(tg, x, aux, aux2);
         else aux = pdf_precise<KIND>(tg, x);
 
-        Real hist[NL];
+        // Lag history: between steps H[LAGPAD + k] = y_{t-1-k}.  The LAGPAD slots in front let a group of
+        // LAGPAD steps write its samples at static indices and shift the window once per group
+        // (NL/LAGPAD register moves per step instead of NL).  Kept in float: it only feeds the float
+        // lag products and the head/tail sums.
+        float H[NL + LAGPAD];
         float P[NL];
 #pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            P[k] = 0.0f;
-            hist[k] = (Real)0;
-        }
+        for (int k = 0; k < NL; ++k) P[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NL + LAGPAD; ++k) H[k] = 0.0f;
         if (NLAG > 0 && !p.window_start && p.ring != nullptr) {
 #pragma unroll
             for (int k = 0; k < NL; ++k)
-                if (k < (int)p.n_lags) hist[k] = ((const Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch];
+                if (k < (int)p.n_lags)
+                    H[LAGPAD + k] = (float)((const Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch];
         }
 
         double S1 = 0.0, S2 = 0.0;
@@ -104,7 +118,10 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
         (void)cursor;
 
         // One sweep of this chain: global step t.
-        auto one_step = [&](uint64_t t, Real normal, Real uniform) {
+        // SLOT < 0: generic step (shifts the lag window by one).  SLOT = s in [0, LAGPAD): step s of a
+        // LAGPAD-step group, window shifted once by the caller after the group.
+        auto one_step = [&](auto slot_tag, uint64_t t, Real normal, Real uniform) {
+            constexpr int SLOT = decltype(slot_tag)::value;
             uint64_t slot = 0;
             if constexpr (INJ || STORE) slot = ((t - t_begin) * p.n_coords + coord) * nc + ch;
             if constexpr (INJ) {
@@ -139,11 +156,16 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
             s1 += (float)y;
             s2 = __builtin_fmaf((float)y, (float)y, s2);
             if constexpr (NLAG > 0) {
+                constexpr int BASE = SLOT < 0 ? LAGPAD : LAGPAD - SLOT;
 #pragma unroll
-                for (int k = 0; k < NL; ++k) P[k] = __builtin_fmaf((float)y, (float)hist[k], P[k]);
+                for (int k = 0; k < NL; ++k) P[k] = __builtin_fmaf((float)y, H[BASE + k], P[k]);
+                if constexpr (SLOT < 0) {
 #pragma unroll
-                for (int k = NL - 1; k > 0; --k) hist[k] = hist[k - 1];
-                hist[0] = y;
+                    for (int k = NL - 1; k > 0; --k) H[LAGPAD + k] = H[LAGPAD + k - 1];
+                    H[LAGPAD] = (float)y;
+                } else {
+                    H[BASE - 1] = (float)y;
+                }
             }
             if constexpr (STORE) {
                 if (p.samples != nullptr && valid) ((Real *)p.samples)[slot] = x;
@@ -188,53 +210,79 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
             s2 = 0.0f;
         };
 
+        // LAGPAD / 2 whole Philox blocks starting at blk0: steps 2*blk0 .. 2*blk0 + LAGPAD - 1
+        auto lag_group = [&](uint64_t blk0, auto seq) {
+            auto body = [&](auto j_tag) {
+                constexpr int J = decltype(j_tag)::value;
+                Real z0, z1, u0, u1;
+                draw_pair(blk0 + J, z0, z1, u0, u1);
+                one_step(std::integral_constant<int, 2 * J>{}, (blk0 + J) << 1, z0, u0);
+                one_step(std::integral_constant<int, 2 * J + 1>{}, ((blk0 + J) << 1) + 1, z1, u1);
+            };
+            expand_sequence(body, seq);
+        };
+
         // Steps [ta, tb): an odd first step and an even last step are the halves of a Philox
         // block; everything between runs whole blocks with no per-step range test.
         auto run_steps = [&](uint64_t ta, uint64_t tb) {
             if (ta >= tb) return;
             Real z0, z1, u0, u1;
             uint64_t blk = ta >> 1;
+            constexpr std::integral_constant<int, -1> GEN{};
             if (ta & 1) {
                 draw_pair(blk, z0, z1, u0, u1);
-                one_step(ta, z1, u1);
+                one_step(GEN, ta, z1, u1);
                 ++blk;
             }
             const uint64_t full_end = tb >> 1;
             while (blk < full_end) {
                 uint64_t stop = (blk | 63u) + 1; // the float partial sums are folded into FP64 every <= 128 steps
                 if (stop > full_end) stop = full_end;
+                if constexpr (NLAG > 0) {
+                    // groups of LAGPAD steps with static lag-window indices
+                    for (; blk + LAGPAD / 2 <= stop; blk += LAGPAD / 2) {
+                        lag_group(blk, std::make_integer_sequence<int, LAGPAD / 2>{});
+#pragma unroll
+                        for (int j = NL + LAGPAD - 1; j >= LAGPAD; --j) H[j] = H[j - LAGPAD];
+                    }
+                }
                 for (; blk < stop; ++blk) {
                     draw_pair(blk, z0, z1, u0, u1);
-                    one_step(blk << 1, z0, u0);
-                    one_step((blk << 1) + 1, z1, u1);
+                    one_step(GEN, blk << 1, z0, u0);
+                    one_step(GEN, (blk << 1) + 1, z1, u1);
                 }
                 flush();
             }
             if (tb & 1) {
                 draw_pair(blk, z0, z1, u0, u1);
-                one_step(tb - 1, z0, u0);
+                one_step(GEN, tb - 1, z0, u0);
             }
             flush();
         };
 
-        // Phase 1: the first NLAG steps of a window, after which the ring holds
-        // exactly the window's first NLAG samples (the "head" sums A_i).
+        // Phase 0: the first n_lags steps of a window, after which the lag window holds exactly the
+        // window's first n_lags samples (the "head" sums A_i).  Phase 1: the rest.  One loop so that
+        // the step code exists once.
         uint64_t t_mid = t_begin;
         if constexpr (NLAG > 0) {
-            if (p.window_start && p.n_steps >= (uint64_t)p.n_lags) {
-                t_mid = t_begin + p.n_lags;
-                run_steps(t_begin, t_mid);
+            if (p.window_start && p.n_steps >= (uint64_t)p.n_lags) t_mid = t_begin + p.n_lags;
+        }
+#pragma unroll 1
+        for (int phase = 0; phase < 2; ++phase) {
+            run_steps(phase == 0 ? t_begin : t_mid, phase == 0 ? t_mid : t_end);
+            if constexpr (NLAG > 0) {
+                if (phase == 0 && t_mid != t_begin) {
 #pragma unroll
-                for (int k = 0; k < NL; ++k) {
-                    if (k < (int)p.n_lags) {
-                        // hist[k] = y_{n_lags-1-k}
-                        const double w = wave_sum(valid ? (double)hist[k] : 0.0);
-                        if (lane == 0) sred[wave][3 + p.n_lags + (p.n_lags - 1 - k)] += (double)w;
+                    for (int k = 0; k < NL; ++k) {
+                        if (k < (int)p.n_lags) {
+                            // H[LAGPAD + k] = y_{n_lags-1-k}
+                            const double w = wave_sum(valid ? (double)H[LAGPAD + k] : 0.0);
+                            if (lane == 0) sred[wave][3 + p.n_lags + (p.n_lags - 1 - k)] += (double)w;
+                        }
                     }
                 }
             }
         }
-        run_steps(t_mid, t_end);
 
         // clamped (invalid) lanes replayed chain 0 on a possibly stale read: they never store
         if (valid) *state = x;
@@ -242,7 +290,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
         if (NLAG > 0 && p.ring != nullptr && valid) {
 #pragma unroll
             for (int k = 0; k < NL; ++k)
-                if (k < (int)p.n_lags) ((Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch] = hist[k];
+                if (k < (int)p.n_lags)
+                    ((Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch] = (Real)H[LAGPAD + k];
         }
 
         // wave reductions -> per-wave LDS accumulators (only lane 0 of a wave touches its row)
@@ -257,8 +306,9 @@ __global__ __launch_bounds__(CHAIN_BLOCK) void chain_kernel(const ChainParams p)
 #pragma unroll
             for (int k = 0; k < NL; ++k) {
                 if (k < (int)p.n_lags) {
+                    // FP64 across chains: sums must not depend on how chains fall into waves / GPUs
                     const double pk = wave_sum(valid ? (double)P[k] : 0.0);
-                    const double zk = wave_sum(valid ? (double)hist[k] : 0.0);
+                    const double zk = wave_sum(valid ? (double)H[LAGPAD + k] : 0.0);
                     if (lane == 0) {
                         sred[wave][3 + k] += (double)pk;
                         sred[wave][3 + 2 * p.n_lags + k] += (double)zk;
