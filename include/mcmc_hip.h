@@ -136,15 +136,18 @@ int mcmc_stats_finalize(const double *stats, uint32_t n_lags, uint64_t n_chains,
                         double center, mcmc_chain_summary *out, double *rho /* [n_lags] or NULL */);
 
 /* The library's random draws as device arrays [n_steps][n_chains] (any pointer
- * may be NULL): N(0,1) proposals and accept uniforms in (0,1] of coordinate
- * `coord` of chains chain_offset.., and the two angle uniforms of the S_AB
- * kernel.  Replaces RandomNormal/RandomUniform (stepsize/include/random.hpp:
- * 7-19) and curand_normal/curand_uniform (Metropolis.cuh:43,47;
- * IntegrateSAB.cuh:51-52): Philox4x32-10 keyed by seed, counter = (chain,
- * coord, step), so the values do not depend on launch geometry or GPU count. */
+ * may be NULL), for chains chain_offset.. and coordinate / nucleon `coord`:
+ *   normals, uniforms          N(0,1) proposals and accept uniforms in (0,1) of the chain kernels
+ *                              (mcmc_chain_run, warm-up, R2): packed stream, 3 Philox blocks per 8 steps
+ *   angle_u0, angle_u1         the two angle uniforms of the S_AB kernel
+ *   sab_normals, sab_uniforms  proposals and accept uniforms in (0,1] of the S_AB kernel
+ * Replaces RandomNormal/RandomUniform (stepsize/include/random.hpp:7-19) and
+ * curand_normal/curand_uniform (Metropolis.cuh:43,47; IntegrateSAB.cuh:51-52):
+ * Philox4x32-10 keyed by seed, counter = (chain, coord, step block, stream tag), so the
+ * values do not depend on launch geometry or GPU count.                     */
 int mcmc_launch_draws(uint64_t seed, uint64_t chain_offset, uint64_t n_chains, uint32_t coord, uint64_t step_offset,
                       uint64_t n_steps, int math_mode, float *normals, float *uniforms, float *angle_u0,
-                      float *angle_u1, void *stream);
+                      float *angle_u1, float *sab_normals, float *sab_uniforms, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* Layer A.2 -- xsection kernels (device pointers, reference layouts).   */

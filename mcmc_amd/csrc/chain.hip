@@ -127,31 +127,60 @@ extern "C" int mcmc_stats_finalize(const double *stats, uint32_t n_lags, uint64_
 // (stepsize/include/random.hpp:7-19) and curand_normal / curand_uniform
 // (Metropolis.cuh:43,47; IntegrateSAB.cuh:51-52) are replaced by.
 namespace {
+// normals / uniforms: the packed MH stream of the chain kernels (TAG_MH);
+// u0s / u1s: the angle uniforms of the S_AB kernel (TAG_ANGLE);
+// sab_normals / sab_uniforms: the MH stream of the S_AB kernel (TAG_SAB_MH).
 template <int MATH>
 __global__ void draws_kernel(uint64_t seed, uint64_t chain_offset, uint64_t n_chains, uint32_t coord, uint64_t step_offset,
-                             uint64_t n_steps, float *normals, float *uniforms, float *u0s, float *u1s)
+                             uint64_t n_steps, float *normals, float *uniforms, float *u0s, float *u1s, float *sab_normals,
+                             float *sab_uniforms)
 {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chains) return;
     const uint64_t ta = step_offset, tb = step_offset + n_steps;
     if (n_steps == 0) return;
+    const uint64_t id = chain_offset + c;
+    if (normals || uniforms) {
+        for (uint64_t g = ta >> 3; g <= ((tb - 1) >> 3); ++g) {
+            uint32_t sp[3];
+            u32x4 w[4];
+            w[0] = pair_words<0>(seed, id, coord, g, sp);
+            w[1] = pair_words<1>(seed, id, coord, g, sp);
+            w[2] = pair_words<2>(seed, id, coord, g, sp);
+            w[3] = pair_words<3>(seed, id, coord, g, sp);
+            for (int j = 0; j < 4; ++j) {
+                float z0, z1, v0, v1;
+                pair_draws_f32<MATH, false>(w[j], 0.0f, z0, z1, v0, v1);
+                const uint64_t t0 = (g << 3) + 2 * j;
+                if (t0 >= ta && t0 < tb) {
+                    if (normals) normals[(t0 - ta) * n_chains + c] = z0;
+                    if (uniforms) uniforms[(t0 - ta) * n_chains + c] = v0;
+                }
+                if (t0 + 1 >= ta && t0 + 1 < tb) {
+                    if (normals) normals[(t0 + 1 - ta) * n_chains + c] = z1;
+                    if (uniforms) uniforms[(t0 + 1 - ta) * n_chains + c] = v1;
+                }
+            }
+        }
+    }
+    if (!(u0s || u1s || sab_normals || sab_uniforms)) return;
     for (uint64_t blk = ta >> 1; blk <= ((tb - 1) >> 1); ++blk) {
-        const u32x4 r = draw_block(seed, chain_offset + c, coord, blk, 0u);
-        const u32x4 q = draw_block(seed, chain_offset + c, coord, blk, 1u);
+        const u32x4 r = draw_block(seed, id, coord, blk, TAG_SAB_MH);
+        const u32x4 q = draw_block(seed, id, coord, blk, TAG_ANGLE);
         float z0, z1;
         box_muller<MATH>(r.x, r.y, z0, z1);
         const uint64_t te = blk << 1;
         if (te >= ta) {
             const uint64_t o = (te - ta) * n_chains + c;
-            if (normals) normals[o] = z0;
-            if (uniforms) uniforms[o] = u01(r.z);
+            if (sab_normals) sab_normals[o] = z0;
+            if (sab_uniforms) sab_uniforms[o] = u01(r.z);
             if (u0s) u0s[o] = u01(q.x);
             if (u1s) u1s[o] = u01(q.y);
         }
         if (te + 1 < tb) {
             const uint64_t o = (te + 1 - ta) * n_chains + c;
-            if (normals) normals[o] = z1;
-            if (uniforms) uniforms[o] = u01(r.w);
+            if (sab_normals) sab_normals[o] = z1;
+            if (sab_uniforms) sab_uniforms[o] = u01(r.w);
             if (u0s) u0s[o] = u01(q.z);
             if (u1s) u1s[o] = u01(q.w);
         }
@@ -161,16 +190,17 @@ __global__ void draws_kernel(uint64_t seed, uint64_t chain_offset, uint64_t n_ch
 
 extern "C" int mcmc_launch_draws(uint64_t seed, uint64_t chain_offset, uint64_t n_chains, uint32_t coord,
                                  uint64_t step_offset, uint64_t n_steps, int math_mode, float *normals, float *uniforms,
-                                 float *angle_u0, float *angle_u1, void *stream)
+                                 float *angle_u0, float *angle_u1, float *sab_normals, float *sab_uniforms, void *stream)
 {
     if (n_chains == 0) return set_error(MCMC_EINVAL, "n_chains must be > 0");
     const dim3 grid((unsigned)((n_chains + 255) / 256)), block(256);
     if (math_mode == MCMC_MATH_FAST)
         hipLaunchKernelGGL(draws_kernel<MCMC_MATH_FAST>, grid, block, 0, (hipStream_t)stream, seed, chain_offset, n_chains,
-                           coord, step_offset, n_steps, normals, uniforms, angle_u0, angle_u1);
+                           coord, step_offset, n_steps, normals, uniforms, angle_u0, angle_u1, sab_normals, sab_uniforms);
     else
         hipLaunchKernelGGL(draws_kernel<MCMC_MATH_PRECISE>, grid, block, 0, (hipStream_t)stream, seed, chain_offset,
-                           n_chains, coord, step_offset, n_steps, normals, uniforms, angle_u0, angle_u1);
+                           n_chains, coord, step_offset, n_steps, normals, uniforms, angle_u0, angle_u1, sab_normals,
+                           sab_uniforms);
     MCMC_HIP_CHECK(hipGetLastError());
     return MCMC_OK;
 }

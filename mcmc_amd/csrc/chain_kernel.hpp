@@ -119,8 +119,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 2 : 1) void chain_kernel(co
 
         // One sweep of this chain: global step t.
         // SLOT < 0: generic step (shifts the lag window by one).  SLOT = s in [0, LAGPAD): step s of a
-        // LAGPAD-step group, window shifted once by the caller after the group.
-        auto one_step = [&](auto slot_tag, uint64_t t, Real normal, Real uniform) {
+        // run of LAGPAD steps, window shifted once by the caller after the run.
+        auto one_step = [&](auto slot_tag, uint64_t t, Real normal, Real uniform) __attribute__((always_inline)) {
             constexpr int SLOT = decltype(slot_tag)::value;
             uint64_t slot = 0;
             if constexpr (INJ || STORE) slot = ((t - t_begin) * p.n_coords + coord) * nc + ch;
@@ -173,90 +173,69 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 2 : 1) void chain_kernel(co
             }
         };
 
-        // The draws of steps 2*blk (z0, u0) and 2*blk + 1 (z1, u1): one Philox block.
-        auto draw_pair = [&](uint64_t blk, Real &z0, Real &z1, Real &u0, Real &u1) {
-            z0 = z1 = u0 = u1 = (Real)0;
-            if constexpr (!INJ) {
-                const u32x4 r = draw_block(p.seed, gid, coord, blk, 0u);
-                if constexpr (PRESCALED) {
-                    float a, b;
-                    box_muller_scaled(r.x, r.y, scale2, a, b);
-                    z0 = a;
-                    z1 = b;
-                    u0 = u01(r.z);
-                    u1 = u01(r.w);
-                } else if constexpr (sizeof(Real) == 4) {
-                    float a, b;
-                    box_muller<MATH>(r.x, r.y, a, b);
-                    z0 = a;
-                    z1 = b;
-                    u0 = u01(r.z);
-                    u1 = u01(r.w);
-                } else {
-                    double a, b;
-                    box_muller_f64(r.x, r.y, a, b);
-                    z0 = a;
-                    z1 = b;
-                    u0 = (double)r.z * 2.3283064365386963e-10;
-                    u1 = (double)r.w * 2.3283064365386963e-10;
-                }
-            }
-        };
-
-        auto flush = [&]() {
+        auto flush = [&]() __attribute__((always_inline)) {
             S1 += (double)s1;
             S2 += (double)s2;
             s1 = 0.0f;
             s2 = 0.0f;
         };
 
-        // LAGPAD / 2 whole Philox blocks starting at blk0: steps 2*blk0 .. 2*blk0 + LAGPAD - 1
-        auto lag_group = [&](uint64_t blk0, auto seq) {
-            auto body = [&](auto j_tag) {
+        // One group of 8 steps = 4 step pairs from 3 Philox blocks (device_common.hpp, packed draws).
+        // FULL: every step of the group is inside [ta, tb): no range tests, static lag-window slots
+        // (the window is shifted by LAGPAD = 4 after pairs 1 and 3).  Otherwise (first / last group of a
+        // launch) each step is range-tested and shifts the window itself.
+        auto do_group = [&](auto full_tag, uint64_t g, uint64_t ta, uint64_t tb) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            uint32_t sp[3] = {0u, 0u, 0u};
+            auto body = [&](auto j_tag) __attribute__((always_inline)) {
                 constexpr int J = decltype(j_tag)::value;
-                Real z0, z1, u0, u1;
-                draw_pair(blk0 + J, z0, z1, u0, u1);
-                one_step(std::integral_constant<int, 2 * J>{}, (blk0 + J) << 1, z0, u0);
-                one_step(std::integral_constant<int, 2 * J + 1>{}, ((blk0 + J) << 1) + 1, z1, u1);
-            };
-            expand_sequence(body, seq);
-        };
-
-        // Steps [ta, tb): an odd first step and an even last step are the halves of a Philox
-        // block; everything between runs whole blocks with no per-step range test.
-        auto run_steps = [&](uint64_t ta, uint64_t tb) {
-            if (ta >= tb) return;
-            Real z0, z1, u0, u1;
-            uint64_t blk = ta >> 1;
-            constexpr std::integral_constant<int, -1> GEN{};
-            if (ta & 1) {
-                draw_pair(blk, z0, z1, u0, u1);
-                one_step(GEN, ta, z1, u1);
-                ++blk;
-            }
-            const uint64_t full_end = tb >> 1;
-            while (blk < full_end) {
-                uint64_t stop = (blk | 63u) + 1; // the float partial sums are folded into FP64 every <= 128 steps
-                if (stop > full_end) stop = full_end;
-                if constexpr (NLAG > 0) {
-                    // groups of LAGPAD steps with static lag-window indices
-                    for (; blk + LAGPAD / 2 <= stop; blk += LAGPAD / 2) {
-                        lag_group(blk, std::make_integer_sequence<int, LAGPAD / 2>{});
+                Real z0 = 0, z1 = 0, u0 = 0, u1 = 0;
+                if constexpr (!INJ) {
+                    const u32x4 w = pair_words<J>(p.seed, gid, coord, g, sp);
+                    if constexpr (sizeof(Real) == 4) {
+                        float a, b, c, d;
+                        pair_draws_f32<MATH, PRESCALED>(w, scale2, a, b, c, d);
+                        z0 = a, z1 = b, u0 = c, u1 = d;
+                    } else {
+                        double a, b, c, d;
+                        pair_draws_f64(w, a, b, c, d);
+                        z0 = a, z1 = b, u0 = c, u1 = d;
+                    }
+                }
+                const uint64_t t0 = (g << 3) + 2 * J;
+                if constexpr (FULL) {
+                    one_step(std::integral_constant<int, (2 * J) & (LAGPAD - 1)>{}, t0, z0, u0);
+                    one_step(std::integral_constant<int, (2 * J + 1) & (LAGPAD - 1)>{}, t0 + 1, z1, u1);
+                    if constexpr (NLAG > 0 && (J & 1) == 1) {
 #pragma unroll
                         for (int j = NL + LAGPAD - 1; j >= LAGPAD; --j) H[j] = H[j - LAGPAD];
                     }
+                } else {
+                    constexpr std::integral_constant<int, -1> GEN{};
+                    if (t0 >= ta && t0 < tb) one_step(GEN, t0, z0, u0);
+                    if (t0 + 1 >= ta && t0 + 1 < tb) one_step(GEN, t0 + 1, z1, u1);
                 }
-                for (; blk < stop; ++blk) {
-                    draw_pair(blk, z0, z1, u0, u1);
-                    one_step(GEN, blk << 1, z0, u0);
-                    one_step(GEN, (blk << 1) + 1, z1, u1);
-                }
+            };
+            expand_sequence(body, std::make_integer_sequence<int, 4>{});
+        };
+
+        // Steps [ta, tb)
+        auto run_steps = [&](uint64_t ta, uint64_t tb) __attribute__((always_inline)) {
+            if (ta >= tb) return;
+            uint64_t g = ta >> 3;
+            const uint64_t g_end = (tb + 7) >> 3; // exclusive
+            if ((ta & 7) != 0 || (g << 3) + 8 > tb) {
+                do_group(std::false_type{}, g, ta, tb);
+                ++g;
+            }
+            const uint64_t g_full_end = tb >> 3;
+            while (g < g_full_end) {
+                uint64_t stop = (g | 15u) + 1; // the float partial sums are folded into FP64 every <= 128 steps
+                if (stop > g_full_end) stop = g_full_end;
+                for (; g < stop; ++g) do_group(std::true_type{}, g, ta, tb);
                 flush();
             }
-            if (tb & 1) {
-                draw_pair(blk, z0, z1, u0, u1);
-                one_step(GEN, tb - 1, z0, u0);
-            }
+            if (g < g_end) do_group(std::false_type{}, g, ta, tb);
             flush();
         };
 

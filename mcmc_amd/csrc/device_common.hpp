@@ -41,8 +41,12 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
     return c;
 }
 
-// Draw convention (DESIGN.md "RNG"): ctr = (id_lo, coord<<8 | id_hi8, blk_lo,
-// tag<<24 | blk_hi24), blk = step >> 1; tag 0 = MH draws, 1 = angle draws.
+// Draw convention (DESIGN.md "RNG"): ctr = (id_lo, coord<<8 | id_hi8, blk_lo, tag<<24 | blk_hi24).
+//   TAG_MH      packed MH draws of the chain kernels: 3 blocks per group of 8 steps (below)
+//   TAG_ANGLE   angle uniforms of the S_AB kernel, blk = step >> 1
+//   TAG_SAB_MH  MH draws of the S_AB kernel, blk = step >> 1
+constexpr uint32_t TAG_MH = 0u, TAG_ANGLE = 1u, TAG_SAB_MH = 2u;
+
 __device__ __forceinline__ u32x4 draw_block(uint64_t seed, uint64_t id, uint32_t coord, uint64_t blk, uint32_t tag)
 {
     u32x4 c;
@@ -59,8 +63,89 @@ __device__ __forceinline__ float u01(uint32_t r)
     return __builtin_fmaf((float)r, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
-// Box-Muller pair from two raw words.  FAST uses the hardware log2/sqrt and
-// v_sin/v_cos (argument in revolutions, so no 2*pi multiply or reduction).
+// ---- packed MH draws -------------------------------------------------
+// A group of 8 steps (4 step pairs) costs 3 Philox blocks instead of 4: every word gives a 23-bit
+// field from its TOP 23 bits, and the 4 low bytes of each block form a "spare" word; the fourth
+// pair is made of the three spares.  A field becomes a float in [1,2) with ONE v_alignbit_b32
+// (0x7F : word >> 9 is exponent 0 + 23 mantissa bits).
+__device__ __forceinline__ float mant12(uint32_t w)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_alignbit(0x7Fu, w, 9u));
+}
+
+constexpr float MANT_OPEN = 0.99999994f; // 1 - 2^-24: mant12(w) - MANT_OPEN = (2m+1) 2^-24 in (0,1)
+
+__device__ __forceinline__ uint32_t spare_bytes(const u32x4 &w)
+{
+    // v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0c = zero
+    const uint32_t t01 = __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0400u);
+    const uint32_t t23 = __builtin_amdgcn_perm(w.w, w.z, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+}
+
+// the four words of step pair 3 of a group from the spares of its blocks 0..2
+__device__ __forceinline__ u32x4 spare_pair(uint32_t s0, uint32_t s1, uint32_t s2)
+{
+    u32x4 r;
+    r.x = s0;
+    r.y = s1;
+    r.z = s2;
+    const uint32_t t = __builtin_amdgcn_perm(s1, s0, 0x0c04000cu); // 0 | s0.b0 << 8 | s1.b0 << 16
+    r.w = __builtin_amdgcn_perm(s2, t, 0x04020100u);               // ... | s2.b0 << 24
+    return r;
+}
+
+// Words of step pair J (0..3) of group g; sp[] carries the spares across J = 0..2 -> 3.
+template <int J>
+__device__ __forceinline__ u32x4 pair_words(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, uint32_t (&sp)[3])
+{
+    if constexpr (J < 3) {
+        const u32x4 w = draw_block(seed, id, coord, 3 * g + J, TAG_MH);
+        sp[J] = spare_bytes(w);
+        return w;
+    } else {
+        return spare_pair(sp[0], sp[1], sp[2]);
+    }
+}
+
+// Draws of one step pair from its words: normals (z0 even step, z1 odd step) and accept uniforms.
+//   MATH FAST + SCALED: returns step * z (scale2 = -2 ln2 step^2 folded into the radius)
+template <int MATH, bool SCALED>
+__device__ __forceinline__ void pair_draws_f32(const u32x4 &w, float scale2, float &z0, float &z1, float &u0, float &u1)
+{
+    const float f1 = mant12(w.x), f2 = mant12(w.y);
+    if constexpr (MATH == MCMC_MATH_FAST) {
+        // -2 ln u = (-2 ln2) log2 u; v_sin/v_cos take revolutions and reduce the argument themselves
+        const float rad = __builtin_amdgcn_sqrtf((SCALED ? scale2 : -1.3862943611198906f) * __builtin_amdgcn_logf(f1 - MANT_OPEN));
+        z0 = rad * __builtin_amdgcn_cosf(f2);
+        z1 = rad * __builtin_amdgcn_sinf(f2);
+    } else {
+        const float rad = sqrtf(-2.0f * logf(f1 - MANT_OPEN));
+        float sn, cs;
+        sincospif(2.0f * (f2 - 1.0f), &sn, &cs);
+        z0 = rad * cs;
+        z1 = rad * sn;
+    }
+    u0 = mant12(w.z) - MANT_OPEN;
+    u1 = mant12(w.w) - MANT_OPEN;
+}
+
+// FP64 flavour (stepsize CPU rule): uniforms in [0,1) like std::uniform_real_distribution (random.hpp:10)
+__device__ __forceinline__ void pair_draws_f64(const u32x4 &w, double &z0, double &z1, double &u0, double &u1)
+{
+    const double a = (double)(mant12(w.x) - MANT_OPEN);
+    const double b = (double)(mant12(w.y) - 1.0f);
+    const double rad = sqrt(-2.0 * log(a));
+    double sn, cs;
+    sincospi(2.0 * b, &sn, &cs);
+    z0 = rad * cs;
+    z1 = rad * sn;
+    u0 = (double)(mant12(w.z) - 1.0f);
+    u1 = (double)(mant12(w.w) - 1.0f);
+}
+
+// Box-Muller pair from two raw 32-bit words (S_AB kernel streams).  FAST uses the hardware
+// log2/sqrt and v_sin/v_cos (argument in revolutions, so no 2*pi multiply or reduction).
 template <int MATH>
 __device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float &z_even, float &z_odd)
 {
@@ -77,27 +162,6 @@ __device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float &z_ev
         z_even = rad * c;
         z_odd = rad * s;
     }
-}
-
-// FAST path with the proposal width folded into the radius: returns step * z for both normals
-// (scale2 = -2 ln2 * step^2), one multiply less per proposal than z followed by step * z.
-__device__ __forceinline__ void box_muller_scaled(uint32_t r0, uint32_t r1, float scale2, float &dz_even, float &dz_odd)
-{
-    const float u1 = u01(r0), u2 = u01(r1);
-    const float rad = __builtin_amdgcn_sqrtf(scale2 * __builtin_amdgcn_logf(u1));
-    dz_even = rad * __builtin_amdgcn_cosf(u2);
-    dz_odd = rad * __builtin_amdgcn_sinf(u2);
-}
-
-__device__ __forceinline__ void box_muller_f64(uint32_t r0, uint32_t r1, double &z_even, double &z_odd)
-{
-    const double u1 = ((double)r0 + 0.5) * 2.3283064365386963e-10;
-    const double u2 = ((double)r1 + 0.5) * 2.3283064365386963e-10;
-    const double rad = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi(2.0 * u2, &s, &c);
-    z_even = rad * c;
-    z_odd = rad * s;
 }
 
 // ---------------------------------------------------------------------

@@ -11,6 +11,8 @@
 //                     positions broadcast from LDS.
 //   row reductions  : device Average (Statistics.cuh:23-25) in FP64, fixed order.
 #pragma once
+#include <type_traits>
+
 #include "device_common.hpp"
 
 namespace mcmc {
@@ -59,7 +61,7 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
     const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
     const uint64_t gid = p.event_offset + e;
 
-    auto one = [&](uint64_t t, float z, float u) {
+    auto one = [&](uint64_t t, float z, float u) __attribute__((always_inline)) {
         if constexpr (INJ) {
             const float *d = p.injected + e * p.inj_stride + ((t - ta) * nN + n) * 2;
             z = d[0];
@@ -75,19 +77,35 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
         }
     };
 
-    if (p.samples > 0) {
-        for (uint64_t blk = ta >> 1; blk <= ((tb - 1) >> 1); ++blk) {
+    // groups of 8 steps = 4 step pairs from 3 Philox blocks (packed draws, device_common.hpp)
+    auto do_group = [&](auto full_tag, uint64_t g) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        uint32_t sp[3] = {0u, 0u, 0u};
+        auto body = [&](auto j_tag) __attribute__((always_inline)) {
+            constexpr int J = decltype(j_tag)::value;
             float z0 = 0, z1 = 0, u0 = 0, u1 = 0;
             if constexpr (!INJ) {
-                const u32x4 r = draw_block(p.seed, gid, n, blk, 0u);
-                box_muller<MATH>(r.x, r.y, z0, z1);
-                u0 = u01(r.z);
-                u1 = u01(r.w);
+                const u32x4 w = pair_words<J>(p.seed, gid, n, g, sp);
+                pair_draws_f32<MATH, false>(w, 0.0f, z0, z1, u0, u1);
             }
-            const uint64_t te = blk << 1;
-            if (te >= ta) one(te, z0, u0);
-            if (te + 1 < tb) one(te + 1, z1, u1);
+            const uint64_t t0 = (g << 3) + 2 * J;
+            if (FULL || (t0 >= ta && t0 < tb)) one(t0, z0, u0);
+            if (FULL || (t0 + 1 >= ta && t0 + 1 < tb)) one(t0 + 1, z1, u1);
+        };
+        body(std::integral_constant<int, 0>{});
+        body(std::integral_constant<int, 1>{});
+        body(std::integral_constant<int, 2>{});
+        body(std::integral_constant<int, 3>{});
+    };
+    if (p.samples > 0) {
+        uint64_t g = ta >> 3;
+        const uint64_t g_end = (tb + 7) >> 3, g_full_end = tb >> 3;
+        if ((ta & 7) != 0 || (g << 3) + 8 > tb) {
+            do_group(std::false_type{}, g);
+            ++g;
         }
+        for (; g < g_full_end; ++g) do_group(std::true_type{}, g);
+        if (g < g_end) do_group(std::false_type{}, g);
     }
     if (valid) {
         p.prevSample[idx] = x;
@@ -360,11 +378,11 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                 const TgtLds tl = tgt[n];
                 float z0 = 0, z1 = 0, u0 = 0, u1 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
                 if constexpr (!INJ) {
-                    const u32x4 r = draw_block(p.seed, gid, n, blk, 0u);
+                    const u32x4 r = draw_block(p.seed, gid, n, blk, TAG_SAB_MH);
                     box_muller<MATH>(r.x, r.y, z0, z1);
                     u0 = u01(r.z);
                     u1 = u01(r.w);
-                    const u32x4 q = draw_block(p.seed, gid, n, blk, 1u);
+                    const u32x4 q = draw_block(p.seed, gid, n, blk, TAG_ANGLE);
                     a0 = u01(q.x);
                     a1 = u01(q.y);
                     a2 = u01(q.z);

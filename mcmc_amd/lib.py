@@ -93,7 +93,8 @@ def _load():
     lib.mcmc_stats_finalize.argtypes = [P(C.c_double), C.c_uint32, C.c_uint64, C.c_uint64, C.c_double,
                                         P(ChainSummary), P(C.c_double)]
     lib.mcmc_launch_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
     lib.mcmc_xs_workspace_bytes.restype = C.c_size_t
     lib.mcmc_xs_workspace_bytes.argtypes = [P(XsArgs)]
     lib.mcmc_launch_init_sample_array.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint64, C.c_void_p]

@@ -54,7 +54,9 @@ ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uin
  * restatement used to cross-check the device code.
  *   key = (seed_lo, seed_hi)
  *   ctr = (id_lo, (coord << 8) | id_hi8, blk_lo, (tag << 24) | blk_hi24)
- * where blk = step >> 1.  tag 0: MH draws, tag 1: angle draws.            */
+ * tag 0: MH draws of the chain kernels, packed: 3 blocks per group of 8 steps.
+ * tag 1: angle draws of the S_AB kernel, blk = step >> 1.
+ * tag 2: MH draws of the S_AB kernel, blk = step >> 1.                      */
 static void orc_block(uint64_t seed, uint64_t id, uint32_t coord, uint64_t blk, uint32_t tag, uint32_t out[4])
 {
     uint32_t ctr[4], key[2];
@@ -73,12 +75,87 @@ static float orc_u01_f32(uint32_t r)
     return fmaf((float)r, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
-/* MH draws for step t of chain (id, coord): normal and accept uniform.
- * Box-Muller over (r0, r1): even step gets the cosine branch, odd the sine. */
+/* Packed MH draws (tag 0).  Steps are grouped by 8 (group g = t >> 3), a group
+ * into 4 step pairs j = (t >> 1) & 3.  Blocks B_0..B_2 = Philox(blk = 3 g + j)
+ * serve pairs 0..2: each of the 4 words gives a 23-bit field from its TOP 23
+ * bits; the 4 low bytes of a block are its "spare" word
+ *   S_j = w0.b0 | w1.b0 << 8 | w2.b0 << 16 | w3.b0 << 24.
+ * Pair 3 is made of the spares: fields from the top 23 bits of S_0, S_1, S_2
+ * and of (S_0.b0 << 8 | S_1.b0 << 16 | S_2.b0 << 24).  So 128 Philox bits
+ * carry 5 1/3 draws of 23 bits instead of 4 of 32.
+ * Field m -> uniform (2m + 1) 2^-24 in (0,1) (never 0, never 1); the
+ * Box-Muller angle uses the fraction m 2^-23 itself (a grid symmetric under
+ * theta -> theta + 1/2, so proposals stay exactly symmetric).
+ * Pair fields: m[0] radius, m[1] angle, m[2] / m[3] accept uniform of the
+ * even / odd step.                                                         */
+static uint32_t orc_spare(const uint32_t w[4])
+{
+    return (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8) | ((w[2] & 0xFFu) << 16) | ((w[3] & 0xFFu) << 24);
+}
+
+static void orc_pair_fields(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, uint32_t m[4])
+{
+    uint64_t g = t >> 3;
+    uint32_t j = (uint32_t)(t >> 1) & 3u;
+    uint32_t w[4];
+    if (j < 3) {
+        orc_block(seed, id, coord, 3 * g + j, 0u, w);
+    } else {
+        uint32_t sp[3];
+        for (uint32_t k = 0; k < 3; ++k) {
+            orc_block(seed, id, coord, 3 * g + k, 0u, w);
+            sp[k] = orc_spare(w);
+        }
+        w[0] = sp[0]; w[1] = sp[1]; w[2] = sp[2];
+        w[3] = ((sp[0] & 0xFFu) << 8) | ((sp[1] & 0xFFu) << 16) | ((sp[2] & 0xFFu) << 24);
+    }
+    for (int k = 0; k < 4; ++k) m[k] = w[k] >> 9;
+}
+
+static float orc_field_uniform(uint32_t m) { return (float)(2 * m + 1) * 5.9604644775390625e-08f; } /* exact */
+
+/* MH draws for step t of chain (id, coord): normal and accept uniform. */
 ORC_API void orc_mh_draws_f32(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, float *normal, float *uniform)
 {
+    uint32_t m[4];
+    orc_pair_fields(seed, id, coord, t, m);
+    float u1 = orc_field_uniform(m[0]);
+    float rad = sqrtf(-2.0f * logf(u1));
+    double ang = 2.0 * M_PI * ((double)m[1] * 1.1920928955078125e-07);
+    if (t & 1u) {
+        *normal = rad * (float)sin(ang);
+        *uniform = orc_field_uniform(m[3]);
+    } else {
+        *normal = rad * (float)cos(ang);
+        *uniform = orc_field_uniform(m[2]);
+    }
+}
+
+/* FP64 flavour for the stepsize (CPU-rule) kernels: the same fields, Box-Muller
+ * in double, uniform m 2^-23 in [0,1) like std::uniform_real_distribution
+ * (stepsize/include/random.hpp:10).                                       */
+ORC_API void orc_mh_draws_f64(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, double *normal, double *uniform)
+{
+    uint32_t m[4];
+    orc_pair_fields(seed, id, coord, t, m);
+    double u1 = (double)orc_field_uniform(m[0]);
+    double rad = sqrt(-2.0 * log(u1));
+    double ang = 2.0 * M_PI * ((double)m[1] * 1.1920928955078125e-07);
+    if (t & 1u) {
+        *normal = rad * sin(ang);
+        *uniform = (double)m[3] * 1.1920928955078125e-07;
+    } else {
+        *normal = rad * cos(ang);
+        *uniform = (double)m[2] * 1.1920928955078125e-07;
+    }
+}
+
+/* S_AB kernel streams: one block per step pair and per tag, 32-bit uniforms.
+ * Box-Muller over (r0, r1): even step gets the cosine branch, odd the sine. */
+ORC_API void orc_sab_mh_draws_f32(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, float *normal, float *uniform)
+{
     uint32_t r[4];
-    orc_block(seed, id, coord, t >> 1, 0u, r);
+    orc_block(seed, id, coord, t >> 1, 2u, r);
     float u1 = orc_u01_f32(r[0]);
     float u2 = orc_u01_f32(r[1]);
     float rad = sqrtf(-2.0f * logf(u1));
@@ -98,26 +175,6 @@ ORC_API void orc_angle_draws_f32(uint64_t seed, uint64_t id, uint32_t coord, uin
     orc_block(seed, id, coord, t >> 1, 1u, r);
     if (t & 1u) { *u0 = orc_u01_f32(r[2]); *u1 = orc_u01_f32(r[3]); }
     else        { *u0 = orc_u01_f32(r[0]); *u1 = orc_u01_f32(r[1]); }
-}
-
-/* FP64 flavour for the stepsize (CPU-rule) kernels: normal from Box-Muller in
- * double, uniform in [0,1) like std::uniform_real_distribution
- * (stepsize/include/random.hpp:10).                                       */
-ORC_API void orc_mh_draws_f64(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, double *normal, double *uniform)
-{
-    uint32_t r[4];
-    orc_block(seed, id, coord, t >> 1, 0u, r);
-    double u1 = ((double)r[0] + 0.5) * 2.3283064365386963e-10;
-    double u2 = ((double)r[1] + 0.5) * 2.3283064365386963e-10;
-    double rad = sqrt(-2.0 * log(u1));
-    double ang = 2.0 * M_PI * u2;
-    if (t & 1u) {
-        *normal = rad * sin(ang);
-        *uniform = (double)r[3] * 2.3283064365386963e-10;
-    } else {
-        *normal = rad * cos(ang);
-        *uniform = (double)r[2] * 2.3283064365386963e-10;
-    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -558,14 +615,34 @@ ORC_API uint64_t orc_baseline_chains_f32(uint64_t chain0, uint64_t n_chains, int
         for (int d = 0; d < nC; ++d) {
             float x = x0;
             float invP = 1.f / orc_pdf_f32(kind, p0, p1, x);
-            for (uint64_t t = 0; t < sweeps; ++t) {
-                float n, u;
-                uint8_t bit;
-                orc_mh_draws_f32(seed, c, (uint32_t)d, step_offset + t, &n, &u);
-                orc_mh_step_f32(&tg, &x, &invP, step, n, u, &bit);
-                acc += bit;
-                s1 += x;
-                s2 += (double)x * x;
+            uint64_t t = step_offset, tb = step_offset + sweeps;
+            while (t < tb) {
+                /* one group of 8 steps = 3 Philox blocks, generated once (as the kernel does) */
+                uint64_t g = t >> 3;
+                uint32_t w[4][4], sp[3];
+                for (uint32_t k = 0; k < 3; ++k) {
+                    orc_block(seed, c, (uint32_t)d, 3 * g + k, 0u, w[k]);
+                    sp[k] = orc_spare(w[k]);
+                }
+                w[3][0] = sp[0]; w[3][1] = sp[1]; w[3][2] = sp[2];
+                w[3][3] = ((sp[0] & 0xFFu) << 8) | ((sp[1] & 0xFFu) << 16) | ((sp[2] & 0xFFu) << 24);
+                for (uint32_t j = 0; j < 4; ++j) {
+                    float u1 = orc_field_uniform(w[j][0] >> 9);
+                    float rad = sqrtf(-2.0f * logf(u1));
+                    float ang = 6.283185307179586f * ((float)(w[j][1] >> 9) * 1.1920928955078125e-07f);
+                    float z[2] = {rad * cosf(ang), rad * sinf(ang)};
+                    float u[2] = {orc_field_uniform(w[j][2] >> 9), orc_field_uniform(w[j][3] >> 9)};
+                    for (uint32_t h = 0; h < 2; ++h) {
+                        uint64_t ts = (g << 3) + 2 * j + h;
+                        if (ts < t || ts >= tb) continue;
+                        uint8_t bit;
+                        orc_mh_step_f32(&tg, &x, &invP, step, z[h], u[h], &bit);
+                        acc += bit;
+                        s1 += x;
+                        s2 += (double)x * x;
+                    }
+                }
+                t = (g + 1) << 3;
             }
         }
     }

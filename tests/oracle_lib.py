@@ -76,6 +76,12 @@ class Oracle:
                                   C.byref(n), C.byref(u))
         return n.value, u.value
 
+    def sab_mh_draws_f32(self, seed, chain, coord, t):
+        n, u = C.c_float(), C.c_float()
+        self.lib.orc_sab_mh_draws_f32(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(coord), C.c_uint64(t),
+                                      C.byref(n), C.byref(u))
+        return n.value, u.value
+
     def angle_draws_f32(self, seed, chain, coord, t):
         a, b = C.c_float(), C.c_float()
         self.lib.orc_angle_draws_f32(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(coord), C.c_uint64(t),

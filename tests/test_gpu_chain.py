@@ -88,21 +88,26 @@ def test_fp32_gpu_rule_injected_matches_a5(dev, oracle, mode, target):
 
 
 def test_philox_draws_match_oracle(dev, oracle):
-    """RNG layer: device Philox + Box-Muller vs the oracle's independent restatement."""
+    """RNG layer: device Philox + packed fields + Box-Muller vs the oracle's independent restatement
+    (all three streams; offsets chosen so that groups of 8 steps are cut at both ends)."""
     from mcmc_amd import lib as L
-    n_chains, n_steps, coord, seed, off = 64, 33, 2, 314159265, 7
+    n_chains, n_steps, coord, seed, off = 64, 45, 2, 314159265, 5
     for math, tol in ((L.MATH_PRECISE, 2e-6), (L.MATH_FAST, 2e-5)):
-        bufs = [torch.zeros((n_steps, n_chains), dtype=torch.float32, device=dev) for _ in range(4)]
+        bufs = [torch.zeros((n_steps, n_chains), dtype=torch.float32, device=dev) for _ in range(6)]
         L.check(L.lib.mcmc_launch_draws(seed, 1000, n_chains, coord, off, n_steps, math,
                                         *[C.c_void_p(t.data_ptr()) for t in bufs], None))
         torch.cuda.synchronize()
-        z, u, a0, a1 = [t.cpu().numpy() for t in bufs]
+        z, u, a0, a1, sz, su = [t.cpu().numpy() for t in bufs]
+        assert u.min() > 0.0 and u.max() < 1.0
         for c in (0, 5, 63):
             for i in range(n_steps):
                 zn, un = oracle.mh_draws_f32(seed, 1000 + c, coord, off + i)
                 b0, b1 = oracle.angle_draws_f32(seed, 1000 + c, coord, off + i)
-                assert u[i, c] == un and a0[i, c] == b0 and a1[i, c] == b1  # integer -> float path is exact
+                szn, sun = oracle.sab_mh_draws_f32(seed, 1000 + c, coord, off + i)
+                # integer -> float paths are exact
+                assert u[i, c] == un and a0[i, c] == b0 and a1[i, c] == b1 and su[i, c] == sun
                 assert abs(z[i, c] - zn) <= tol * max(1.0, abs(zn))
+                assert abs(sz[i, c] - szn) <= tol * max(1.0, abs(szn))
 
 
 def test_philox_mode_trajectory_matches_oracle_on_device_draws(dev, oracle):
@@ -112,7 +117,7 @@ def test_philox_mode_trajectory_matches_oracle_on_device_draws(dev, oracle):
     z = torch.zeros((n_steps, n_chains), dtype=torch.float32, device=dev)
     u = torch.zeros((n_steps, n_chains), dtype=torch.float32, device=dev)
     L.check(L.lib.mcmc_launch_draws(seed, 0, n_chains, 0, 0, n_steps, L.MATH_PRECISE, C.c_void_p(z.data_ptr()),
-                                    C.c_void_p(u.data_ptr()), None, None, None))
+                                    C.c_void_p(u.data_ptr()), None, None, None, None, None))
     eng = _engine(dev, n_chains=n_chains, n_coords=1, target=R2WS_REF, step=2.2, precision=32,
                   accept_rule=L.ACCEPT_RECIP, math_mode=L.MATH_PRECISE, seed=seed)
     samples = torch.empty((n_steps, 1, n_chains), dtype=torch.float32, device=dev)

@@ -122,8 +122,9 @@ def test_sab_philox_matches_oracle_on_device_draws(dev, oracle):
     per = []
     for n in range(nN):
         bufs = [torch.zeros((samples, T), dtype=torch.float32, device=dev) for _ in range(4)]
-        L.check(L.lib.mcmc_launch_draws(seed, 0, T, n, 0, samples, L.MATH_PRECISE,
-                                        *[C.c_void_p(t.data_ptr()) for t in bufs], None))
+        a0b, a1b, zb, ub = [C.c_void_p(t.data_ptr()) for t in bufs]
+        L.check(L.lib.mcmc_launch_draws(seed, 0, T, n, 0, samples, L.MATH_PRECISE, None, None, a0b, a1b, zb, ub, None))
+        bufs = [bufs[2], bufs[3], bufs[0], bufs[1]]  # -> z, u, a0, a1 of the S_AB kernel's streams
         per.append([t.cpu().numpy() for t in bufs])
     torch.cuda.synchronize()
     d = np.empty((T, samples, 2, nN, 2), dtype=np.float32)
