@@ -9,7 +9,7 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclu
 LIB = mcmc_amd/libmcmc_hip.so
 
 OBJS = $(OBJ)/chain.o $(OBJ)/chain_kind_0.o $(OBJ)/chain_kind_1.o $(OBJ)/chain_kind_2.o $(OBJ)/chain_kind_3.o \
-       $(OBJ)/xsection.o $(OBJ)/capi.o $(OBJ)/errors.o
+       $(OBJ)/xsection.o $(OBJ)/mvn.o $(OBJ)/capi.o $(OBJ)/errors.o
 HDRS = $(wildcard $(CSRC)/*.hpp) include/mcmc_hip.h
 
 all: $(LIB) drivers oracle

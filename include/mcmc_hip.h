@@ -150,6 +150,48 @@ int mcmc_launch_draws(uint64_t seed, uint64_t chain_offset, uint64_t n_chains, u
                       float *angle_u1, float *sab_normals, float *sab_uniforms, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* Layer A.3 -- correlated Gaussian "stress" target (BASELINE.json configs[4]): n_chains chains in
+ * `dim` dimensions, precision matrix symmetric tridiagonal (e.g. Sigma_ij = rho^|i-j|).  One sweep =
+ * GibbsStep (xsection/include/Metropolis.cuh:69-79): dim single-coordinate MetropolisHastingsSteps
+ * (:40-52) on the coordinate's conditional density, accepted in log space.  A scalar observable
+ * (one coordinate) is tracked per sweep: mean / variance (statistics.hpp:6-34), and the lag-`lag`
+ * autocorrelation (statistics.hpp:36-57) through a ring of the last `lag` observables per chain in
+ * HBM; optional write-back of the observable or of the whole state (coalesced SoA).
+ * No counterpart target exists in the reference; parity is against the oracle's restatement of the
+ * same sweep under injected draws.                                                            */
+#define MCMC_MVN_STATS_LEN 6 /* sum y, sum y^2, accepts, P_L = sum y_t y_{t-L}, HEAD, TAIL (first / last L samples) */
+typedef struct {
+    uint64_t n_chains;
+    uint32_t dim;            /* multiple of 8, <= 64                                              */
+    uint32_t observable;     /* coordinate whose series is tracked                                */
+    uint64_t n_steps;        /* sweeps in this launch                                             */
+    float step_size;         /* proposal width (Metropolis.cuh:43)                                */
+    float center;            /* y = x_obs - center is accumulated                                 */
+    const float *q_diag;     /* HOST [dim]   Q[i][i]                                              */
+    const float *q_off;      /* HOST [dim-1] Q[i][i+1]                                            */
+    int32_t math_mode;       /* mcmc_math_mode                                                    */
+    uint32_t lag;            /* L >= 1                                                            */
+    uint64_t seed, step_offset, chain_offset;
+    uint64_t window_begin;   /* first sweep of the statistics window this launch belongs to       */
+    uint64_t window_end;     /* one past its last sweep                                           */
+    float *state;            /* dev [dim][n_chains], in/out                                       */
+    float *ring;             /* dev [lag][n_chains]: row (t mod lag) holds y_t                    */
+    float *samples_obs;      /* dev [n_steps][n_chains] observable write-back, or NULL            */
+    float *samples_full;     /* dev [n_steps][dim][n_chains] state write-back, or NULL            */
+    const float *inj;        /* dev [n_steps][dim][2][n_chains] injected (normal, uniform), or NULL */
+    uint8_t *accept_bits;    /* dev [n_steps][dim][n_chains], or NULL                             */
+    double *stats;           /* dev [MCMC_MVN_STATS_LEN], overwritten                             */
+    void *workspace;
+    size_t workspace_bytes;
+} mcmc_mvn_args;
+
+size_t mcmc_mvn_workspace_bytes(const mcmc_mvn_args *a);
+int mcmc_mvn_run(const mcmc_mvn_args *a, void *stream);
+/* Host finalisation of the window's summed statistics (statistics.hpp:6-57 for the one lag). */
+int mcmc_mvn_finalize(const double *stats, uint64_t n_chains, uint32_t dim, uint64_t n_sweeps, uint32_t lag,
+                      double center, mcmc_chain_summary *out, double *rho_lag);
+
+/* ------------------------------------------------------------------ */
 /* Layer A.2 -- xsection kernels (device pointers, reference layouts).   */
 typedef struct {
     uint32_t nNucleonsA;        /* main.cu:43 */

@@ -184,6 +184,59 @@ class XsEngine:
         return self.resultSAB, self.sabMean, (self.hits if dmax2 is not None else None)
 
 
+def ar1_precision(dim, rho):
+    """Tridiagonal precision matrix of Sigma_ij = rho^|i-j| -> (q_diag[dim], q_off[dim-1])."""
+    c = 1.0 / (1.0 - rho * rho)
+    d = np.full(dim, (1.0 + rho * rho) * c, dtype=np.float32)
+    d[0] = d[-1] = c
+    return d, np.full(dim - 1, -rho * c, dtype=np.float32)
+
+
+class MvnEngine:
+    """Layer A.3 (`mcmc_mvn_run`): chains on a correlated Gaussian with tridiagonal precision, lag-L
+    autocorrelation of one coordinate through an HBM ring, optional sample write-back."""
+
+    def __init__(self, n_chains, q_diag, q_off, step, lag, observable=0, math_mode=L.MATH_FAST, seed=314159265,
+                 x0=1.0, chain_offset=0, center=0.0, device="cuda:0"):
+        self.device = torch.device(device)
+        self.q_diag = np.ascontiguousarray(q_diag, dtype=np.float32)
+        self.q_off = np.ascontiguousarray(q_off, dtype=np.float32)
+        self.dim, self.n_chains, self.lag = len(self.q_diag), int(n_chains), int(lag)
+        self.state = torch.full((self.dim, self.n_chains), float(x0), dtype=torch.float32, device=self.device)
+        self.ring = torch.zeros((self.lag, self.n_chains), dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros((6,), dtype=torch.float64, device=self.device)
+        a = self.args = L.MvnArgs()
+        a.n_chains, a.dim, a.observable = self.n_chains, self.dim, observable
+        a.step_size, a.center = float(step), float(center)
+        a.q_diag, a.q_off = self.q_diag.ctypes.data, self.q_off.ctypes.data
+        a.math_mode, a.lag = math_mode, self.lag
+        a.seed, a.step_offset, a.chain_offset = seed, 0, chain_offset
+        a.state, a.ring, a.stats = self.state.data_ptr(), self.ring.data_ptr(), self.stats.data_ptr()
+        nbytes = _lib.mcmc_mvn_workspace_bytes(C.byref(a))
+        self.workspace = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=self.device)
+        a.workspace, a.workspace_bytes = self.workspace.data_ptr(), nbytes
+        self.steps_done = 0
+
+    def run(self, n_steps, window=None, samples_obs=None, samples_full=None, inj=None, accept_bits=None):
+        """n_steps sweeps; window = (begin, end) global sweep indices of the statistics window (default: this
+        launch alone).  Returns the device stats tensor [6] of THIS launch."""
+        a = self.args
+        a.n_steps, a.step_offset = int(n_steps), self.steps_done
+        wb, we = window if window is not None else (self.steps_done, self.steps_done + int(n_steps))
+        a.window_begin, a.window_end = int(wb), int(we)
+        a.samples_obs, a.samples_full, a.inj, a.accept_bits = _p(samples_obs), _p(samples_full), _p(inj), _p(accept_bits)
+        L.check(_lib.mcmc_mvn_run(C.byref(a), _stream()))
+        self.steps_done += int(n_steps)
+        return self.stats
+
+    def summary(self, stats_host, n_sweeps, n_chains=None):
+        st = np.ascontiguousarray(stats_host, dtype=np.float64)
+        out, rho = L.ChainSummary(), C.c_double()
+        L.check(_lib.mcmc_mvn_finalize(st.ctypes.data_as(C.POINTER(C.c_double)), n_chains or self.n_chains, self.dim,
+                                       int(n_sweeps), self.lag, float(self.args.center), C.byref(out), C.byref(rho)))
+        return {"mean": out.mean, "variance": out.variance, "acceptance": out.acceptance, "rho_lag": rho.value}
+
+
 # --- host statistics with the reference's arithmetic -------------------------
 def _f32(x):
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -45,7 +45,7 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
 //   TAG_MH      packed MH draws of the chain kernels: 3 blocks per group of 8 steps (below)
 //   TAG_ANGLE   angle uniforms of the S_AB kernel, blk = step >> 1
 //   TAG_SAB_MH  MH draws of the S_AB kernel, blk = step >> 1
-constexpr uint32_t TAG_MH = 0u, TAG_ANGLE = 1u, TAG_SAB_MH = 2u;
+constexpr uint32_t TAG_MH = 0u, TAG_ANGLE = 1u, TAG_SAB_MH = 2u; // (3 = TAG_MVN, mvn_kernel.hpp)
 
 __device__ __forceinline__ u32x4 draw_block(uint64_t seed, uint64_t id, uint32_t coord, uint64_t blk, uint32_t tag)
 {
@@ -97,15 +97,22 @@ __device__ __forceinline__ u32x4 spare_pair(uint32_t s0, uint32_t s1, uint32_t s
 
 // Words of step pair J (0..3) of group g; sp[] carries the spares across J = 0..2 -> 3.
 template <int J>
-__device__ __forceinline__ u32x4 pair_words(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, uint32_t (&sp)[3])
+__device__ __forceinline__ u32x4 pair_words_tag(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, uint32_t tag,
+                                                uint32_t (&sp)[3])
 {
     if constexpr (J < 3) {
-        const u32x4 w = draw_block(seed, id, coord, 3 * g + J, TAG_MH);
+        const u32x4 w = draw_block(seed, id, coord, 3 * g + J, tag);
         sp[J] = spare_bytes(w);
         return w;
     } else {
         return spare_pair(sp[0], sp[1], sp[2]);
     }
+}
+
+template <int J>
+__device__ __forceinline__ u32x4 pair_words(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, uint32_t (&sp)[3])
+{
+    return pair_words_tag<J>(seed, id, coord, g, TAG_MH, sp);
 }
 
 // Draws of one step pair from its words: normals (z0 even step, z1 odd step) and accept uniforms.

@@ -1,0 +1,136 @@
+// mvn.hip -- Layer A.3: many chains on a correlated Gaussian target with tridiagonal precision
+// (the BASELINE "stress" configuration), host side: checks, launch, fixed-order reduction,
+// finalisation of the lag-L autocorrelation.
+#include "host_common.hpp"
+#include "mvn_kernel.hpp"
+
+using namespace mcmc;
+
+namespace {
+
+uint32_t mvn_grid(uint64_t n_chains)
+{
+    const uint64_t tiles = (n_chains + MVN_BLOCK - 1) / MVN_BLOCK;
+    return (uint32_t)(tiles < 1024 ? tiles : 1024);
+}
+
+__global__ __launch_bounds__(256) void mvn_finalize_kernel(const double *partials, double *stats, int nblocks)
+{
+    __shared__ double sh[256];
+    const int i = blockIdx.x;
+    double tot = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) tot += partials[(uint64_t)b * MVN_STATS + i];
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stats[i] = sh[0];
+}
+
+} // namespace
+
+extern "C" size_t mcmc_mvn_workspace_bytes(const mcmc_mvn_args *a)
+{
+    if (!a) return 0;
+    return (size_t)mvn_grid(a->n_chains) * MVN_STATS * sizeof(double);
+}
+
+extern "C" int mcmc_mvn_run(const mcmc_mvn_args *a, void *stream)
+{
+    if (!a) return set_error(MCMC_EINVAL, "null args");
+    if (a->n_chains == 0) return set_error(MCMC_EINVAL, "n_chains must be > 0");
+    if (a->n_chains > (1ull << 40)) return set_error(MCMC_EINVAL, "n_chains must be <= 2^40");
+    if (a->dim == 0 || a->dim > MVN_MAX_DIM || (a->dim & 7u)) return set_error(MCMC_EINVAL, "dim must be a multiple of 8, <= 64");
+    if (a->observable >= a->dim) return set_error(MCMC_EINVAL, "observable must be a coordinate index < dim");
+    if (a->lag == 0) return set_error(MCMC_EINVAL, "lag must be >= 1");
+    if (!a->q_diag || !a->q_off) return set_error(MCMC_EINVAL, "q_diag / q_off (host arrays) are null");
+    if (!a->state || !a->ring || !a->stats) return set_error(MCMC_EINVAL, "state, ring and stats must be device pointers");
+    if (a->math_mode != MCMC_MATH_PRECISE && a->math_mode != MCMC_MATH_FAST) return set_error(MCMC_EINVAL, "bad math_mode");
+    if (a->step_offset < a->window_begin || a->step_offset + a->n_steps > a->window_end)
+        return set_error(MCMC_EINVAL, "the launch [step_offset, step_offset + n_steps) must lie inside [window_begin, window_end)");
+    if (a->window_end - a->window_begin < a->lag) return set_error(MCMC_EINVAL, "the statistics window must hold at least `lag` sweeps");
+    for (uint32_t i = 0; i < a->dim; ++i)
+        if (!(a->q_diag[i] > 0.0f)) return set_error(MCMC_EINVAL, "q_diag must be positive");
+    const size_t need = mcmc_mvn_workspace_bytes(a);
+    if (!a->workspace || a->workspace_bytes < need) return set_error(MCMC_ENOMEM, "workspace smaller than mcmc_mvn_workspace_bytes()");
+
+    MvnParams p{};
+    p.n_chains = a->n_chains;
+    p.n_steps = a->n_steps;
+    p.seed = a->seed;
+    p.step_offset = a->step_offset;
+    p.chain_offset = a->chain_offset;
+    p.window_begin = a->window_begin;
+    p.window_end = a->window_end;
+    p.dim = a->dim;
+    p.observable = a->observable;
+    p.lag = a->lag;
+    p.n_tiles = (uint32_t)((a->n_chains + MVN_BLOCK - 1) / MVN_BLOCK);
+    p.ring_row0 = (uint32_t)(a->step_offset % a->lag);
+    p.step = a->step_size;
+    p.center = a->center;
+    p.state = a->state;
+    p.ring = a->ring;
+    p.samples_obs = a->samples_obs;
+    p.samples_full = a->samples_full;
+    p.inj = a->inj;
+    p.accept_bits = a->accept_bits;
+    p.partials = (double *)a->workspace;
+    for (uint32_t i = 0; i < a->dim; ++i) {
+        p.q_diag[i] = a->q_diag[i];
+        p.q_off[i] = i + 1 < a->dim ? a->q_off[i] : 0.0f;
+    }
+
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(mvn_grid(a->n_chains)), block(MVN_BLOCK);
+    const size_t lds = sizeof(float) * (size_t)a->dim * MVN_BLOCK;
+    const bool inj = a->inj != nullptr, store = a->samples_full != nullptr || a->accept_bits != nullptr;
+#define MCMC_MVN_LAUNCH(MATH, INJ, STORE)                                                                        \
+    do {                                                                                                         \
+        auto k = mvn_kernel<MATH, INJ, STORE>;                                                                   \
+        if (lds > 48 * 1024)                                                                                     \
+            MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k, grid, block, lds, s, p);                                                           \
+    } while (0)
+    if (a->math_mode == MCMC_MATH_FAST) {
+        if (inj) MCMC_MVN_LAUNCH(MCMC_MATH_FAST, true, true);
+        else if (store) MCMC_MVN_LAUNCH(MCMC_MATH_FAST, false, true);
+        else MCMC_MVN_LAUNCH(MCMC_MATH_FAST, false, false);
+    } else {
+        if (inj) MCMC_MVN_LAUNCH(MCMC_MATH_PRECISE, true, true);
+        else if (store) MCMC_MVN_LAUNCH(MCMC_MATH_PRECISE, false, true);
+        else MCMC_MVN_LAUNCH(MCMC_MATH_PRECISE, false, false);
+    }
+#undef MCMC_MVN_LAUNCH
+    MCMC_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(mvn_finalize_kernel, dim3(MVN_STATS), dim3(256), 0, s, (const double *)a->workspace, a->stats,
+                       (int)grid.x);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+// statistics.hpp:6-57 for ONE lag from the window's summed vector (the six entries add over launches
+// and devices): mean, variance (n-1), acceptance, and rho_L = [sum (y_t - mu)(y_{t+L} - mu) / (cnt - 1)] / var.
+extern "C" int mcmc_mvn_finalize(const double *stats, uint64_t n_chains, uint32_t dim, uint64_t n_sweeps, uint32_t lag,
+                                 double center, mcmc_chain_summary *out, double *rho_lag)
+{
+    if (!stats || !out) return set_error(MCMC_EINVAL, "null pointer");
+    if (n_chains == 0 || n_sweeps == 0 || dim == 0) return set_error(MCMC_EINVAL, "empty window");
+    const double N = (double)n_chains * (double)n_sweeps;
+    const double mu = stats[0] / N;
+    out->mean = mu + center;
+    out->variance = (stats[1] - N * mu * mu) / (N - 1.0);
+    out->acceptance = stats[2] / (N * dim);
+    double r = 0.0;
+    if (n_sweeps > lag) {
+        const double cnt = (double)n_chains * (double)(n_sweeps - lag);
+        const double F = stats[0] - stats[5], B = stats[0] - stats[4];
+        const double cov = stats[3] - mu * (F + B) + cnt * mu * mu;
+        r = cov / (cnt - 1.0) / out->variance;
+    }
+    if (rho_lag) *rho_lag = r;
+    out->tau_int = 1.0 + 2.0 * r; // only the one tracked lag: a lower bound of 1 + 2 sum rho_k
+    return MCMC_OK;
+}

@@ -1,0 +1,177 @@
+// mvn_kernel.hpp -- the "stress" configuration (BASELINE.json configs[4]):
+// many chains on a D-dimensional correlated Gaussian target (D <= 64, multiple of 8) whose
+// precision matrix is symmetric tridiagonal -- e.g. Sigma_ij = rho^|i-j| -- with a scalar
+// observable written back every sweep, a lag-L autocorrelation accumulator fed from a ring of the
+// last L observables in HBM, and optional full-state structure-of-arrays sample write-back.
+//
+// One sweep is the reference's GibbsStep (xsection/include/Metropolis.cuh:69-79): the coordinates
+// are updated one after the other by MetropolisHastingsStep (:40-52), here with the coordinate's
+// conditional log-density and LOG-SPACE acceptance: for x_i -> x_i + d
+//     log p(x') - log p(x) = -d (h_i + Q_ii d / 2),   h_i = Q_ii x_i + Q_i,i-1 x_i-1 + Q_i,i+1 x_i+1
+// and the move is taken when log U <= that difference.
+//
+// Layout: one chain per lane, the chain's D coordinates in LDS as x[j][lane] (conflict-free, 64 KiB
+// per 256-thread block at D = 64, two blocks per CU); a coordinate update reads its right neighbour
+// and writes itself.  The band of Q sits in the kernel arguments (scalar loads).  HBM traffic per
+// chain and sweep: observable 4 B + ring read 4 B + ring write 4 B (+ 4 D B with full write-back).
+#pragma once
+#include <type_traits>
+
+#include "device_common.hpp"
+
+namespace mcmc {
+
+constexpr int MVN_BLOCK = 256;
+constexpr int MVN_MAX_DIM = 64;
+constexpr uint32_t TAG_MVN = 3u;
+constexpr int MVN_STATS = 6; // S1, S2, accepts, P_L, HEAD, TAIL
+
+struct MvnParams {
+    uint64_t n_chains, n_steps;
+    uint64_t seed, step_offset, chain_offset;
+    uint64_t window_begin, window_end;
+    uint32_t dim, observable, lag, n_tiles;
+    uint32_t ring_row0; // step_offset mod lag
+    float step, center;
+    float *state;
+    float *ring;
+    float *samples_obs;
+    float *samples_full;
+    const float *inj;
+    uint8_t *accept_bits;
+    double *partials; // [gridDim.x][MVN_STATS]
+    float q_diag[MVN_MAX_DIM];
+    float q_off[MVN_MAX_DIM]; // q_off[i] = Q[i][i+1]; q_off[dim-1] = 0
+};
+
+template <int MATH, bool INJ, bool STORE>
+__global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
+{
+    extern __shared__ __align__(16) float xs[]; // [dim][MVN_BLOCK]
+    __shared__ double sred[MVN_BLOCK / 64][MVN_STATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t D = p.dim;
+    const uint64_t nc = p.n_chains;
+    if (tid < (MVN_BLOCK / 64) * MVN_STATS) (&sred[0][0])[tid] = 0.0;
+    __syncthreads();
+
+    const float scale2 = -1.3862943611198906f * p.step * p.step;
+    const uint64_t ta = p.step_offset, tb = p.step_offset + p.n_steps;
+
+    for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        const uint64_t chain = (uint64_t)tile * MVN_BLOCK + tid;
+        const bool valid = chain < nc;
+        const uint64_t ch = valid ? chain : 0;
+        const uint64_t gid = p.chain_offset + ch;
+        for (uint32_t j = 0; j < D; ++j) xs[j * MVN_BLOCK + tid] = p.state[(uint64_t)j * nc + ch];
+
+        double S1 = 0, S2 = 0, PL = 0, HEAD = 0, TAIL = 0;
+        float s1 = 0, s2 = 0, pl = 0, hd = 0, tl = 0;
+        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+        uint64_t wacc = 0;
+
+        uint32_t row = p.ring_row0; // t mod lag, carried instead of a 64-bit modulo per sweep
+        for (uint64_t t = ta; t < tb; ++t) {
+            const uint64_t n0 = t * D; // index of this sweep's first proposal in the chain's draw stream
+            float xm = 0.0f, xc = xs[tid];
+            float olm = 0.0f; // Q[i][i-1]
+            for (uint32_t gi = 0; gi < D / 8; ++gi) {
+                const uint64_t g = (n0 >> 3) + gi;
+                uint32_t sp[3] = {0u, 0u, 0u};
+                auto body = [&](auto j_tag) __attribute__((always_inline)) {
+                    constexpr int J = decltype(j_tag)::value;
+                    float z[2] = {0.0f, 0.0f}, u[2] = {0.0f, 0.0f};
+                    if constexpr (!INJ) {
+                        const u32x4 w = pair_words_tag<J>(p.seed, gid, 0u, g, TAG_MVN, sp);
+                        pair_draws_f32<MATH, MATH == MCMC_MATH_FAST>(w, scale2, z[0], z[1], u[0], u[1]);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t i = gi * 8 + 2 * J + h;
+                        uint64_t slot = 0;
+                        if constexpr (INJ || STORE) slot = ((t - ta) * D + i) * nc + ch;
+                        float dz;
+                        if constexpr (INJ) {
+                            const float *d = p.inj + 2 * slot - ch; // [step][coord][2][chain]
+                            dz = p.step * d[0];
+                            u[h] = d[nc];
+                        } else if constexpr (MATH == MCMC_MATH_FAST) {
+                            dz = z[h]; // already step * z
+                        } else {
+                            dz = p.step * z[h];
+                        }
+                        const float xp = (i + 1 < D) ? xs[(i + 1) * MVN_BLOCK + tid] : 0.0f;
+                        const float qd = p.q_diag[i], orr = p.q_off[i];
+                        const float hsum = qd * xc + olm * xm + orr * xp;
+                        const float t1 = hsum + (0.5f * qd) * dz;
+                        const float delta = -(dz * t1);
+                        float lu;
+                        if constexpr (MATH == MCMC_MATH_FAST) lu = 0.6931471805599453f * __builtin_amdgcn_logf(u[h]);
+                        else lu = logf(u[h]);
+                        const bool take = lu <= delta;
+                        const float xn = take ? xc + dz : xc;
+                        xs[i * MVN_BLOCK + tid] = xn;
+                        wacc += (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take) & vmask);
+                        if constexpr (STORE) {
+                            if (p.accept_bits != nullptr && valid) p.accept_bits[slot] = take ? 1 : 0;
+                        }
+                        xm = xn;
+                        xc = xp;
+                        olm = orr;
+                    }
+                };
+                body(std::integral_constant<int, 0>{});
+                body(std::integral_constant<int, 1>{});
+                body(std::integral_constant<int, 2>{});
+                body(std::integral_constant<int, 3>{});
+            }
+            // the observable of this sweep, its statistics and the lag-L product through the HBM ring
+            const float xo = xs[p.observable * MVN_BLOCK + tid];
+            const float y = xo - p.center;
+            s1 += y;
+            s2 = __builtin_fmaf(y, y, s2);
+            const uint64_t w = t - p.window_begin;
+            float *slot_ring = p.ring + (uint64_t)row * nc + ch;
+            row = row + 1 == p.lag ? 0u : row + 1;
+            if (w >= p.lag) pl = __builtin_fmaf(y, *slot_ring, pl); // row (t mod L) still holds y_{t-L}
+            else hd += y;
+            if (t + p.lag >= p.window_end) tl += y;
+            if (valid) *slot_ring = y;
+            if (p.samples_obs != nullptr && valid) p.samples_obs[(t - ta) * nc + ch] = xo;
+            if constexpr (STORE) {
+                if (p.samples_full != nullptr && valid)
+                    for (uint32_t j = 0; j < D; ++j)
+                        p.samples_full[((t - ta) * D + j) * nc + ch] = xs[j * MVN_BLOCK + tid];
+            }
+            if (((t - ta) & 127u) == 127u) {
+                S1 += (double)s1, S2 += (double)s2, PL += (double)pl, HEAD += (double)hd, TAIL += (double)tl;
+                s1 = s2 = pl = hd = tl = 0.0f;
+            }
+        }
+        S1 += (double)s1, S2 += (double)s2, PL += (double)pl, HEAD += (double)hd, TAIL += (double)tl;
+        if (valid)
+            for (uint32_t j = 0; j < D; ++j) p.state[(uint64_t)j * nc + ch] = xs[j * MVN_BLOCK + tid];
+
+        const double r0 = wave_sum(valid ? S1 : 0.0), r1 = wave_sum(valid ? S2 : 0.0), r3 = wave_sum(valid ? PL : 0.0),
+                     r4 = wave_sum(valid ? HEAD : 0.0), r5 = wave_sum(valid ? TAIL : 0.0);
+        if (lane == 0) {
+            sred[wave][0] += r0;
+            sred[wave][1] += r1;
+            sred[wave][2] += (double)wacc;
+            sred[wave][3] += r3;
+            sred[wave][4] += r4;
+            sred[wave][5] += r5;
+        }
+    }
+    __syncthreads();
+    if (tid < MVN_STATS) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < MVN_BLOCK / 64; ++w) tot += sred[w][tid];
+        p.partials[(uint64_t)blockIdx.x * MVN_STATS + tid] = tot;
+    }
+}
+
+} // namespace mcmc

@@ -40,6 +40,19 @@ class ChainSummary(C.Structure):
     _fields_ = [("mean", C.c_double), ("variance", C.c_double), ("acceptance", C.c_double), ("tau_int", C.c_double)]
 
 
+class MvnArgs(C.Structure):
+    _fields_ = [
+        ("n_chains", C.c_uint64), ("dim", C.c_uint32), ("observable", C.c_uint32), ("n_steps", C.c_uint64),
+        ("step_size", C.c_float), ("center", C.c_float), ("q_diag", C.c_void_p), ("q_off", C.c_void_p),
+        ("math_mode", C.c_int32), ("lag", C.c_uint32),
+        ("seed", C.c_uint64), ("step_offset", C.c_uint64), ("chain_offset", C.c_uint64),
+        ("window_begin", C.c_uint64), ("window_end", C.c_uint64),
+        ("state", C.c_void_p), ("ring", C.c_void_p), ("samples_obs", C.c_void_p), ("samples_full", C.c_void_p),
+        ("inj", C.c_void_p), ("accept_bits", C.c_void_p), ("stats", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class XsArgs(C.Structure):
     _fields_ = [
         ("nNucleonsA", C.c_uint32), ("nNucleonsB", C.c_uint32), ("totalThreads", C.c_uint64),
@@ -69,6 +82,7 @@ class Config(C.Structure):
 # Every symbol include/mcmc_hip.h declares (tests/test_abi.py checks the header against this list).
 EXPORTS = [
     "mcmc_chain_workspace_bytes", "mcmc_chain_run", "mcmc_stats_finalize", "mcmc_launch_draws",
+    "mcmc_mvn_workspace_bytes", "mcmc_mvn_run", "mcmc_mvn_finalize",
     "mcmc_xs_workspace_bytes", "mcmc_launch_init_sample_array", "mcmc_launch_warmup_metropolis",
     "mcmc_launch_integrate_r2", "mcmc_launch_integrate_sab", "mcmc_launch_row_mean_f32",
     "mcmc_row_mean_workspace_bytes",
@@ -95,6 +109,11 @@ def _load():
     lib.mcmc_launch_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
+    lib.mcmc_mvn_workspace_bytes.restype = C.c_size_t
+    lib.mcmc_mvn_workspace_bytes.argtypes = [P(MvnArgs)]
+    lib.mcmc_mvn_run.argtypes = [P(MvnArgs), C.c_void_p]
+    lib.mcmc_mvn_finalize.argtypes = [P(C.c_double), C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_double,
+                                      P(ChainSummary), P(C.c_double)]
     lib.mcmc_xs_workspace_bytes.restype = C.c_size_t
     lib.mcmc_xs_workspace_bytes.argtypes = [P(XsArgs)]
     lib.mcmc_launch_init_sample_array.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint64, C.c_void_p]

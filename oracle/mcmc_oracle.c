@@ -599,6 +599,78 @@ ORC_API void orc_cross_sections(const double *b, const double *S, const double *
 }
 
 /* ------------------------------------------------------------------ */
+/* Correlated Gaussian "stress" target (BASELINE.json configs[4]; product spec, no reference
+ * function): precision matrix symmetric tridiagonal (q_diag[dim], q_off[dim-1]).  One sweep =
+ * GibbsStep (xsection/include/Metropolis.cuh:69-79) = dim sequential MetropolisHastingsSteps
+ * (:40-52) on the conditional density of the coordinate, accepted in log space:
+ *   d = step * normal;  h = Q_ii x_i + Q_i,i-1 x_i-1 + Q_i,i+1 x_i+1;
+ *   take  <=>  log U <= -(d * (h + (0.5 Q_ii) d)).
+ * draws: [sweep][coord][2] (normal, uniform) or NULL -> the library's packed Philox stream
+ * (tag 3, coord field 0, proposal index n = sweep * dim + i takes the place of the step).
+ * trace (optional) [sweeps][dim] positions after each sweep; bits (optional) [sweeps][dim];
+ * min_margin (optional) = min |log U - delta| over all proposals.                        */
+static void orc_pair_fields_tag(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, uint32_t tag, uint32_t m[4])
+{
+    uint64_t g = t >> 3;
+    uint32_t j = (uint32_t)(t >> 1) & 3u;
+    uint32_t w[4];
+    if (j < 3) {
+        orc_block(seed, id, coord, 3 * g + j, tag, w);
+    } else {
+        uint32_t sp[3];
+        for (uint32_t k = 0; k < 3; ++k) {
+            orc_block(seed, id, coord, 3 * g + k, tag, w);
+            sp[k] = orc_spare(w);
+        }
+        w[0] = sp[0]; w[1] = sp[1]; w[2] = sp[2];
+        w[3] = ((sp[0] & 0xFFu) << 8) | ((sp[1] & 0xFFu) << 16) | ((sp[2] & 0xFFu) << 24);
+    }
+    for (int k = 0; k < 4; ++k) m[k] = w[k] >> 9;
+}
+
+ORC_API uint64_t orc_mvn_chain(int dim, const float *q_diag, const float *q_off, float *x, float step, uint64_t sweeps,
+                               const float *draws, uint64_t seed, uint64_t chain, uint64_t sweep_offset,
+                               float *trace, uint8_t *bits, float *min_margin)
+{
+    uint64_t acc = 0;
+    float mm = INFINITY;
+    for (uint64_t s = 0; s < sweeps; ++s) {
+        for (int i = 0; i < dim; ++i) {
+            float normal, uniform;
+            if (draws) {
+                normal = draws[(s * dim + i) * 2];
+                uniform = draws[(s * dim + i) * 2 + 1];
+            } else {
+                uint64_t n = (sweep_offset + s) * (uint64_t)dim + (uint64_t)i;
+                uint32_t m[4];
+                orc_pair_fields_tag(seed, chain, 0u, n, 3u, m);
+                float u1 = orc_field_uniform(m[0]);
+                float rad = sqrtf(-2.0f * logf(u1));
+                double ang = 2.0 * M_PI * ((double)m[1] * 1.1920928955078125e-07);
+                normal = (n & 1u) ? rad * (float)sin(ang) : rad * (float)cos(ang);
+                uniform = orc_field_uniform((n & 1u) ? m[3] : m[2]);
+            }
+            float d = step * normal;
+            float qd = q_diag[i];
+            float ol = i > 0 ? q_off[i - 1] : 0.0f, orr = i + 1 < dim ? q_off[i] : 0.0f;
+            float xm = i > 0 ? x[i - 1] : 0.0f, xp = i + 1 < dim ? x[i + 1] : 0.0f;
+            float h = qd * x[i] + ol * xm + orr * xp;
+            float t1 = h + (0.5f * qd) * d;
+            float delta = -(d * t1);
+            float lu = logf(uniform);
+            int take = lu <= delta;
+            float gap = fabsf(lu - delta);
+            if (gap < mm) mm = gap;
+            if (take) { x[i] = x[i] + d; acc += 1; }
+            if (bits) bits[s * dim + i] = (uint8_t)take;
+        }
+        if (trace) memcpy(trace + s * dim, x, sizeof(float) * (size_t)dim);
+    }
+    if (min_margin) *min_margin = mm;
+    return acc;
+}
+
+/* ------------------------------------------------------------------ */
 /* CPU baseline helper for bench.py: n_chains independent FP32 chains of the
  * reference GPU step logic (a5/a7) with library Philox draws, nC coordinates
  * each, `sweeps` sweeps; accumulates sum x, sum x^2 and accepts like the

@@ -43,6 +43,7 @@ def load_oracle():
     lib.orc_GammaNN.restype = C.c_float
     lib.orc_integrate_sab_thread.restype = C.c_float
     lib.orc_baseline_chains_f32.restype = C.c_uint64
+    lib.orc_mvn_chain.restype = C.c_uint64
     return lib
 
 
@@ -225,6 +226,24 @@ class Oracle:
 
     def gamma_nn_r2(self, r, sigmaNN=4.3, beta=0.2):
         return self.lib.orc_GammaNNR2(C.c_float(r), C.c_float(sigmaNN), C.c_float(beta))
+
+    def mvn_chain(self, q_diag, q_off, x, step, sweeps, draws=None, seed=0, chain=0, sweep_offset=0):
+        """-> accepted, final x, trace [sweeps][dim], bits [sweeps][dim], min |log U - delta|."""
+        dim = len(q_diag)
+        qd = np.ascontiguousarray(q_diag, dtype=np.float32)
+        qo = np.ascontiguousarray(np.concatenate([q_off, [0.0]]), dtype=np.float32)
+        x = np.array(x, dtype=np.float32)
+        if draws is not None:
+            draws = np.ascontiguousarray(draws, dtype=np.float32)
+            assert draws.size >= sweeps * dim * 2
+        trace = np.empty((sweeps, dim), dtype=np.float32)
+        bits = np.empty((sweeps, dim), dtype=np.uint8)
+        mm = C.c_float()
+        acc = self.lib.orc_mvn_chain(C.c_int(dim), _ptr(qd, C.c_float), _ptr(qo, C.c_float), _ptr(x, C.c_float),
+                                     C.c_float(step), C.c_uint64(sweeps), _ptr(draws, C.c_float), C.c_uint64(seed),
+                                     C.c_uint64(chain), C.c_uint64(sweep_offset), _ptr(trace, C.c_float),
+                                     _ptr(bits, C.c_uint8), C.byref(mm))
+        return acc, x, trace, bits, mm.value
 
     def baseline_chains_f32(self, chain0, n_chains, nC, kind, p0, p1, step, seed, offset, sweeps, x0=1.0):
         s1, s2 = C.c_double(), C.c_double()
