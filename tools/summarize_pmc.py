@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""tools/summarize_pmc.py TAG OUT.json -- condense gpurun_out/prof_TAG (tools/gpu_profile.sh) into the JSON that
+bench.py reads for roofline.traffic, and copy the kernel-trace stats next to it."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, out_path = sys.argv[1], sys.argv[2]
+base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+bench = json.loads(open(os.path.join(base, "trace.json")).read().strip().splitlines()[-1])
+cfg = bench["config"]
+out = {"source": f"tools/gpu_profile.sh {tag}: bench.py --steps 3 --warmup 1, one rocprofv3 run per pass "
+                 "(kernel-trace; SQ+GRBM; FETCH_SIZE; WRITE_SIZE)",
+       "workload": cfg["workload"], "kernel": None, "per_launch": {}}
+for f in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(os.path.join(base, f, f"{f}_counter_collection.csv"))):
+        if "chain_kernel" in r["Kernel_Name"]:
+            out["kernel"] = r["Kernel_Name"]
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        out["per_launch"][k] = sum(v) / len(v)
+kern_ms = None
+for r in csv.DictReader(open(os.path.join(base, "trace", "trace_kernel_stats.csv"))):
+    if "chain_kernel" in r["Name"]:
+        kern_ms = float(r["AverageNs"]) * 1e-6
+p = out["per_launch"]
+props = cfg["chains_per_gpu"] * cfg["coords"] * cfg["sweeps_per_step"]
+cycles = p["GRBM_GUI_ACTIVE"] / 8
+out["derived"] = {
+    "kernel_ms_kernel_trace": kern_ms,
+    "hbm_bytes_per_launch": p["FETCH_SIZE"] * 1024 * 2 + p["WRITE_SIZE"] * 1024,
+    "note_fetch": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); equals the "
+                  "algorithmic state load chains*coords*4 B",
+    "clock_GHz": cycles / (kern_ms * 1e-3) / 1e9 if kern_ms else None,
+    "valu_insts_per_proposal": p["SQ_INSTS_VALU"] * 64 / props,
+    "simd_cycles_per_wave_proposal": cycles * 1024 / (props / 64),
+    "VALUBusy_gfx9_formula_pct": 100 * p["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cycles,
+}
+json.dump(out, open(os.path.join(ROOT, out_path), "w"), indent=1)
+shutil.copy(os.path.join(base, "trace", "trace_kernel_stats.csv"), os.path.join(ROOT, out_path.replace(".json", "_kernel_stats.csv")))
+print(json.dumps(out["derived"], indent=1))
