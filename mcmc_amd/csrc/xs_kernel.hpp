@@ -330,7 +330,10 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         uint32_t ncoll = 0;
         for (uint32_t q0 = 0; q0 < JB;) {
             const uint32_t rem = JB - q0;
-            if (rem >= 8) {
+            if (rem >= 16) {
+                sab_pairs<16, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
+                q0 += 16;
+            } else if (rem >= 8) {
                 sab_pairs<8, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
                 q0 += 8;
             } else if (rem >= 4) {

@@ -2,6 +2,9 @@
 // selection and launches for InitSampleArray / WarmupMetropolis /
 // MCIntegrate_R2 / MCIntegrate_S_AB (xsection/src/main.cu:130-149,197,335) and
 // the device row means that replace the host Average of main.cu:221-223,359.
+#include <cstdio>
+#include <cstdlib>
+
 #include "host_common.hpp"
 #include "xs_kernel.hpp"
 
@@ -102,6 +105,12 @@ size_t sab_lds_bytes(int G, uint32_t nA, uint32_t nB, bool hits)
 
 SabPlan sab_plan(uint32_t nA, uint32_t nB, bool hits)
 {
+    // tuning hook: MCMC_SAB_PLAN="G,ga_log2" overrides the cost model (tools/bench_xs.py --plan)
+    if (const char *ov = std::getenv("MCMC_SAB_PLAN")) {
+        int g = 0, gl = 0;
+        if (std::sscanf(ov, "%d,%d", &g, &gl) == 2 && (g == 4 || g == 16 || g == 64) && gl >= 0 && (1 << gl) <= g)
+            return SabPlan{g, gl, sab_lds_bytes(g, nA, nB, hits)};
+    }
     const int cand[3] = {4, 16, 64};
     SabPlan best{64, 0, sab_lds_bytes(64, nA, nB, hits)};
     double best_cost = 1e300;
@@ -113,9 +122,16 @@ SabPlan sab_plan(uint32_t nA, uint32_t nB, bool hits)
         for (int gl = 0; (1 << gl) <= G; ++gl) {
             const uint32_t GA = 1u << gl, GB = (uint32_t)G >> gl;
             const uint32_t ia = (nA + GA - 1) / GA, jb = (nB + GB - 1) / GB;
-            const uint32_t passes = jb / 8 + ((jb & 4) ? 1 : 0) + ((jb & 2) ? 1 : 0) + (jb & 1);
-            const double cost = G * (mh + (double)ia * jb * 10.0 + (double)passes * (ia * 3.0 + 16.0) + 12.0 * gl +
-                                     12.0 * __builtin_ctz(G));
+            // pair phase per lane: every pass over the lane's A nucleons holds JC in {16,8,4,2,1} B nucleons;
+            // one iteration costs ~10 issue slots per pair + ~14 of loop / LDS overhead
+            double pair = 0.0;
+            uint32_t rem = jb;
+            for (uint32_t jc = 16; jc >= 1; jc >>= 1)
+                while (rem >= jc) {
+                    pair += (double)ia * (jc * 10.0 + 14.0) + 30.0;
+                    rem -= jc;
+                }
+            const double cost = G * (mh + pair + 12.0 * __builtin_ctz(G));
             if (cost < best_cost) {
                 best_cost = cost;
                 best = SabPlan{G, gl, lds};
