@@ -190,6 +190,8 @@ struct mcmc_handle_s {
     double *d_means;   // [nN] + [4] hits
     void *d_ws;
     size_t ws_bytes;
+    double *d_scan;    // per-launch results of mcmc_run_rms / mcmc_run_sab_scan
+    size_t scan_len;
     uint64_t sweeps_done;
     int uniform_kind;
 };
@@ -252,8 +254,21 @@ void free_handle(mcmc_handle h)
     if (h->d_result) (void)hipFree(h->d_result);
     if (h->d_means) (void)hipFree(h->d_means);
     if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->d_scan) (void)hipFree(h->d_scan);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+int ensure_scan_buffer(mcmc_handle h, size_t len)
+{
+    if (h->scan_len >= len) return MCMC_OK;
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->d_scan) (void)hipFree(h->d_scan);
+    h->d_scan = nullptr;
+    h->scan_len = 0;
+    MCMC_HIP_CHECK(hipMalloc((void **)&h->d_scan, sizeof(double) * len));
+    h->scan_len = len;
+    return MCMC_OK;
 }
 
 } // namespace
@@ -379,48 +394,76 @@ extern "C" int mcmc_integrate_sab(mcmc_handle h, float stepsize, int samples, fl
     return MCMC_OK;
 }
 
-// main.cu:157-286
+// main.cu:157-286.  The reference double-buffers launches against D2H copies and host averages
+// (main.cu:197-240); here every run's per-nucleon mean is reduced on the device into
+// d_scan[run][nN], all runs are queued without a host round trip, and ONE copy ends the loop.
 extern "C" int mcmc_run_rms(mcmc_handle h, float *rms, float *rms_stderr)
 {
     if (!h || !rms || !rms_stderr) return set_error(MCMC_EINVAL, "null pointer");
     const int R = h->cfg.totalRuns;
     if (R <= 0) return set_error(MCMC_EINVAL, "totalRuns must be > 0");
-    std::vector<float> runAverages((size_t)h->nN * R), one(h->nN);
+    if (h->cfg.samplesPerThread <= 0) return set_error(MCMC_EINVAL, "samplesPerThread must be > 0");
+    MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
+    int rc = ensure_scan_buffer(h, (size_t)R * h->nN);
+    if (rc) return rc;
     for (int run = 0; run < R; run++) {
-        int rc = mcmc_integrate_r2(h, h->cfg.stepsize, h->cfg.samplesPerThread, one.data());
+        mcmc_xs_args a = xs_args(h, h->cfg.stepsize);
+        rc = mcmc_launch_integrate_r2(&a, h->d_result, (uint32_t)h->cfg.samplesPerThread, h->d_scan + (size_t)run * h->nN,
+                                      h->stream);
         if (rc) return rc;
-        for (int n = 0; n < h->nN; n++) runAverages[(size_t)n * R + run] = one[n]; // main.cu:221-223
+        h->sweeps_done += (uint64_t)h->cfg.samplesPerThread;
     }
-    for (int n = 0; n < h->nN; n++) { // main.cu:253-258
-        const float *ra = &runAverages[(size_t)n * R];
-        const float finalR2Average = mcmc_Average(ra, R);
-        const float finalR2Stderr = std::sqrt(mcmc_Variance(ra, finalR2Average, R) / R);
+    std::vector<double> m((size_t)R * h->nN);
+    MCMC_HIP_CHECK(hipMemcpyAsync(m.data(), h->d_scan, sizeof(double) * m.size(), hipMemcpyDeviceToHost, h->stream));
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<float> ra(R);
+    for (int n = 0; n < h->nN; n++) { // main.cu:221-223,253-258
+        for (int run = 0; run < R; run++) ra[run] = (float)m[(size_t)run * h->nN + n];
+        const float finalR2Average = mcmc_Average(ra.data(), R);
+        const float finalR2Stderr = std::sqrt(mcmc_Variance(ra.data(), finalR2Average, R) / R);
         rms[n] = std::sqrt(finalR2Average);
         rms_stderr[n] = finalR2Stderr / (2 * rms[n]);
     }
     return MCMC_OK;
 }
 
-// main.cu:289-413
+// main.cu:289-413.  All ndbs x totalRuns launches are queued on the handle's stream, each writing its
+// run mean (and hit counters) into d_scan[dbs][run][1 + 4]; one copy and one synchronisation at the end.
 extern "C" int mcmc_run_sab_scan(mcmc_handle h, float *b_out, float *S_AB, float *S_AB_stderr, double *p_inel, float dmax2)
 {
     if (!h || !b_out || !S_AB || !S_AB_stderr) return set_error(MCMC_EINVAL, "null pointer");
-    const int R = h->cfg.totalRuns;
+    const int R = h->cfg.totalRuns, nb = h->cfg.ndbs;
     if (R <= 0) return set_error(MCMC_EINVAL, "totalRuns must be > 0");
-    std::vector<float> runAverages(R);
-    for (int dbs = 0; dbs < h->cfg.ndbs; dbs++) {
+    if (nb <= 0) return set_error(MCMC_EINVAL, "ndbs must be > 0");
+    if (h->cfg.samplesPerThread <= 0) return set_error(MCMC_EINVAL, "samplesPerThread must be > 0");
+    MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
+    int rc = ensure_scan_buffer(h, (size_t)nb * R * 5);
+    if (rc) return rc;
+    for (int dbs = 0; dbs < nb; dbs++) {
         const float b = h->cfg.b0 + dbs * h->cfg.db; // main.cu:328
+        for (int run = 0; run < R; run++) {
+            double *slot = h->d_scan + ((size_t)dbs * R + run) * 5;
+            mcmc_xs_args a = xs_args(h, h->cfg.stepsize);
+            rc = mcmc_launch_integrate_sab(&a, h->d_result, (uint32_t)h->cfg.samplesPerThread, b, slot,
+                                           p_inel ? slot + 1 : nullptr, dmax2, h->stream);
+            if (rc) return rc;
+            h->sweeps_done += (uint64_t)h->cfg.samplesPerThread;
+        }
+    }
+    std::vector<double> m((size_t)nb * R * 5);
+    MCMC_HIP_CHECK(hipMemcpyAsync(m.data(), h->d_scan, sizeof(double) * m.size(), hipMemcpyDeviceToHost, h->stream));
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<float> runAverages(R);
+    for (int dbs = 0; dbs < nb; dbs++) {
         double inel = 0, nsamp = 0;
         for (int run = 0; run < R; run++) {
-            double hits[4];
-            int rc = mcmc_integrate_sab(h, h->cfg.stepsize, h->cfg.samplesPerThread, b, &runAverages[run],
-                                        p_inel ? hits : nullptr, dmax2);
-            if (rc) return rc;
-            if (p_inel) { inel += hits[1]; nsamp += hits[3]; }
+            const double *slot = &m[((size_t)dbs * R + run) * 5];
+            runAverages[run] = (float)slot[0]; // main.cu:359
+            if (p_inel) { inel += slot[2]; nsamp += slot[4]; }
         }
         const float finalAverage = mcmc_Average(runAverages.data(), R);                  // main.cu:384
         const float finalVariance = mcmc_Variance(runAverages.data(), finalAverage, R);  // main.cu:385
-        b_out[dbs] = b;
+        b_out[dbs] = h->cfg.b0 + dbs * h->cfg.db;
         S_AB[dbs] = finalAverage;
         S_AB_stderr[dbs] = std::sqrt(finalVariance / R);                                 // main.cu:386
         if (p_inel) p_inel[dbs] = nsamp > 0 ? inel / nsamp : 0.0;
