@@ -40,6 +40,10 @@ def main():
         out[f"ref_samples_{tag}"] = samples
         out[f"ref_acceptance_{tag}"] = np.array([ratio])
         out[f"ref_uniforms_used_{tag}"] = np.array([used])
+        # the reference's statistics of its own trajectory (statistics.hpp via main.cpp:27-30)
+        out[f"ref_average_{tag}"] = np.array([ref.average(samples)])
+        out[f"ref_variance_{tag}"] = np.array([ref.variance(samples)])
+        out[f"ref_autocorrelation_{tag}"] = np.array([ref.autocorrelation(samples, k) for k in range(1, 50)])
         # r^2 Gauss(1) (metropolis.hpp:14-17; BASELINE config 0) -- the reference's PDF() is hard-wired to WS,
         # so this trajectory comes from the oracle
         acc, s, bits, used = orc.mh_chain_f64(n, step, O.R2GAUSS, 1.0, 0.0, 1.0, normals, uniforms)
