@@ -22,6 +22,9 @@ $(OBJ):
 $(OBJ)/chain_kind_%.o: $(CSRC)/chain_kind.hip $(HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -DMCMC_KIND=$* -c $< -o $@
 
+$(OBJ)/mvn.o: $(CSRC)/mvn.hip $(HDRS) | $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
+
 $(OBJ)/%.o: $(CSRC)/%.hip $(HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

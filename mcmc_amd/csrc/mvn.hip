@@ -79,8 +79,9 @@ extern "C" int mcmc_mvn_run(const mcmc_mvn_args *a, void *stream)
     p.accept_bits = a->accept_bits;
     p.partials = (double *)a->workspace;
     for (uint32_t i = 0; i < a->dim; ++i) {
-        p.q_diag[i] = a->q_diag[i];
-        p.q_off[i] = i + 1 < a->dim ? a->q_off[i] : 0.0f;
+        p.q_diag[i >> 3][i & 7] = a->q_diag[i];
+        p.q_half[i >> 3][i & 7] = 0.5f * a->q_diag[i];
+        p.q_off[i >> 3][i & 7] = i + 1 < a->dim ? a->q_off[i] : 0.0f;
     }
 
     hipStream_t s = (hipStream_t)stream;

@@ -14,6 +14,8 @@
 // per 256-thread block at D = 64, two blocks per CU); a coordinate update reads its right neighbour
 // and writes itself.  The band of Q sits in the kernel arguments (scalar loads).  HBM traffic per
 // chain and sweep: observable 4 B + ring read 4 B + ring write 4 B (+ 4 D B with full write-back).
+// (A variant with the state in registers and the sweep fully unrolled was measured at D = 64:
+// 241 VGPRs, same occupancy, 3 % faster without and 2x slower with full write-back -- not kept.)
 #pragma once
 #include <type_traits>
 
@@ -26,7 +28,14 @@ constexpr int MVN_MAX_DIM = 64;
 constexpr uint32_t TAG_MVN = 3u;
 constexpr int MVN_STATS = 6; // S1, S2, accepts, P_L, HEAD, TAIL
 
+typedef float f8 __attribute__((ext_vector_type(8)));
+
 struct MvnParams {
+    // band of Q, eight coordinates per vector so that one group of 8 proposals fetches its
+    // coefficients with three s_load_dwordx8 (kernel-argument segment) instead of one load per use
+    alignas(32) f8 q_diag[MVN_MAX_DIM / 8];
+    alignas(32) f8 q_half[MVN_MAX_DIM / 8]; // 0.5 * Q[i][i]
+    alignas(32) f8 q_off[MVN_MAX_DIM / 8];  // Q[i][i+1]; 0 for i = dim-1
     uint64_t n_chains, n_steps;
     uint64_t seed, step_offset, chain_offset;
     uint64_t window_begin, window_end;
@@ -40,8 +49,6 @@ struct MvnParams {
     const float *inj;
     uint8_t *accept_bits;
     double *partials; // [gridDim.x][MVN_STATS]
-    float q_diag[MVN_MAX_DIM];
-    float q_off[MVN_MAX_DIM]; // q_off[i] = Q[i][i+1]; q_off[dim-1] = 0
 };
 
 template <int MATH, bool INJ, bool STORE>
@@ -79,6 +86,7 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
             float olm = 0.0f; // Q[i][i-1]
             for (uint32_t gi = 0; gi < D / 8; ++gi) {
                 const uint64_t g = (n0 >> 3) + gi;
+                const f8 qd8 = p.q_diag[gi], qh8 = p.q_half[gi], qo8 = p.q_off[gi];
                 uint32_t sp[3] = {0u, 0u, 0u};
                 auto body = [&](auto j_tag) __attribute__((always_inline)) {
                     constexpr int J = decltype(j_tag)::value;
@@ -103,9 +111,9 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
                             dz = p.step * z[h];
                         }
                         const float xp = (i + 1 < D) ? xs[(i + 1) * MVN_BLOCK + tid] : 0.0f;
-                        const float qd = p.q_diag[i], orr = p.q_off[i];
+                        const float qd = qd8[2 * J + h], orr = qo8[2 * J + h];
                         const float hsum = qd * xc + olm * xm + orr * xp;
-                        const float t1 = hsum + (0.5f * qd) * dz;
+                        const float t1 = hsum + qh8[2 * J + h] * dz;
                         const float delta = -(dz * t1);
                         float lu;
                         if constexpr (MATH == MCMC_MATH_FAST) lu = 0.6931471805599453f * __builtin_amdgcn_logf(u[h]);
