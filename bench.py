@@ -77,6 +77,28 @@ def cpu_baseline(args, seconds):
                       f"(oracle/mcmc_oracle.c orc_baseline_chains_f32, one thread per core, {dt:.1f} s)"}
 
 
+def cpu_reference_f64(step_size):
+    """The reference's OWN MetropolisHastingsAlgorithm (stepsize/include/metropolis.hpp:28-50, built unmodified into
+    oracle/_ref by oracle/Makefile), one chain on one core, FP64.  Its RNG (clock-seeded mt19937, random.hpp) is
+    replaced by pre-drawn arrays in that build, so the figure EXCLUDES random-number generation."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    if not O.have_ref():
+        return None
+    ref = O.Reference()
+    n = 2_000_000
+    rng = np.random.default_rng(1)
+    z, u = rng.standard_normal(n), rng.random(n)
+    ref.mh(1000, step_size, z, u)
+    t0 = time.perf_counter()
+    ref.mh(n, step_size, z, u)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "proposals/s", "cores": 1, "kind": "reference",
+            "sample": f"{n} iterations of the reference's MetropolisHastingsAlgorithm (FP64, one chain, injected draws: "
+                      f"RNG cost excluded), {dt:.2f} s"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,6 +213,7 @@ def main():
             out["lag49_proposals_per_sec_per_gpu"] = sub * args.coords * 1024 / (ea.elapsed_time(eb) * 1e-3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        out["cpu_reference_f64"] = cpu_reference_f64(args.step_size)
     elif rank == 0:
         out["cpu_baseline"] = None
     if dist is not None:

@@ -37,7 +37,7 @@ extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
     if (!a) return set_error(MCMC_EINVAL, "null args");
     if (a->n_chains == 0 || a->n_coords == 0) return set_error(MCMC_EINVAL, "n_chains and n_coords must be > 0");
     if (a->n_coords > 65535) return set_error(MCMC_EINVAL, "n_coords must be <= 65535");
-    if (a->n_chains > (1ull << 40)) return set_error(MCMC_EINVAL, "n_chains must be <= 2^40");
+    if (a->n_chains > (1ull << 39)) return set_error(MCMC_EINVAL, "n_chains must be <= 2^39");
     if (a->n_lags > MCMC_MAX_LAGS) return set_error(MCMC_EINVAL, "n_lags must be <= MCMC_MAX_LAGS (49)");
     if (!a->state || !a->stats) return set_error(MCMC_EINVAL, "state and stats must be device pointers");
     if ((a->inj_normals == nullptr) != (a->inj_uniforms == nullptr))

@@ -168,8 +168,9 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 2 : 1) void chain_kernel(co
                 }
             }
             if constexpr (STORE) {
-                if (p.samples != nullptr && valid) ((Real *)p.samples)[slot] = x;
-                if (p.accept_bits != nullptr && valid) p.accept_bits[slot] = take ? 1 : 0;
+                // written once, never re-read by this kernel: streaming (nt) stores keep them out of L2's way
+                if (p.samples != nullptr && valid) __builtin_nontemporal_store(x, (Real *)p.samples + slot);
+                if (p.accept_bits != nullptr && valid) __builtin_nontemporal_store((uint8_t)(take ? 1 : 0), p.accept_bits + slot);
             }
         };
 
