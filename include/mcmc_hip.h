@@ -244,6 +244,16 @@ int mcmc_launch_integrate_r2(const mcmc_xs_args *a, float *resultBuffer, uint32_
 int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuffer, uint32_t samples, float impactParameter,
                               double *runMean, double *hits, float dmax2, void *stream);
 
+/* Black-disk inelastic flag alone, for sigma_inel scans (same events, draws and
+ * chain advance as mcmc_launch_integrate_sab; the S_AB product of
+ * IntegrateSAB.cuh:65-78 is not evaluated): per sample "does any A-B pair have
+ * d^2 < dmax2" (visualization/GlauberVisualization.ipynb cell 2).  The pair
+ * scan of an event stops at the first collision found.
+ * hits2: dev [2] doubles: [0] samples with >=1 collision (identical to hits[1]
+ * of mcmc_launch_integrate_sab), [1] samples (totalThreads*samples).        */
+int mcmc_launch_integrate_inel(const mcmc_xs_args *a, uint32_t samples, float impactParameter, double *hits2,
+                               float dmax2, void *stream);
+
 /* Mean over each row of a [rows][cols] float matrix into out[rows] doubles
  * (device Average, Statistics.cuh:23-25; fixed-order FP64 tree).          */
 int mcmc_launch_row_mean_f32(const float *x, uint32_t rows, uint64_t cols, double *out, void *workspace,
@@ -304,6 +314,11 @@ int mcmc_run_rms(mcmc_handle h, float *rms, float *rms_stderr);
  * b, S_AB, S_AB_stderr (main.cu:384-389); p_inel may be NULL (black-disk
  * inelastic probability per b when dmax2 > 0).                              */
 int mcmc_run_sab_scan(mcmc_handle h, float *b, float *S_AB, float *S_AB_stderr, double *p_inel, float dmax2);
+/* The same scan (main.cu:289-413: ndbs impact parameters x totalRuns runs) for the
+ * black-disk inelastic probability alone: p_inel[ndbs] and its run-to-run standard
+ * error (the estimator of main.cu:384-386 applied to the per-run probabilities; 0
+ * when totalRuns == 1).                                                          */
+int mcmc_run_inel_scan(mcmc_handle h, float *b, double *p_inel, double *p_inel_stderr, float dmax2);
 /* Copy the chain state (prevSample, [nNucleons][totalThreads]) to the host. */
 int mcmc_get_state(mcmc_handle h, float *host_out);
 int mcmc_wait(mcmc_handle h);

@@ -183,6 +183,17 @@ class XsEngine:
         self.args.step_offset += int(samples)
         return self.resultSAB, self.sabMean, (self.hits if dmax2 is not None else None)
 
+    def MCIntegrate_Inel(self, samples, impactParameter, dmax2, stepsize=None, injected=None):
+        """Black-disk inelastic flag only (`mcmc_launch_integrate_inel`): returns the device vector
+        [samples with >= 1 collision, samples]."""
+        if stepsize is not None:
+            self.args.stepsize = float(stepsize)
+        self._inject(injected)
+        L.check(_lib.mcmc_launch_integrate_inel(C.byref(self.args), int(samples), float(impactParameter),
+                                                _p(self.hits), float(dmax2), _stream()))
+        self.args.step_offset += int(samples)
+        return self.hits[:2]
+
 
 def ar1_precision(dim, rho):
     """Tridiagonal precision matrix of Sigma_ij = rho^|i-j| -> (q_diag[dim], q_off[dim-1])."""

@@ -471,6 +471,44 @@ extern "C" int mcmc_run_sab_scan(mcmc_handle h, float *b_out, float *S_AB, float
     return MCMC_OK;
 }
 
+// The b scan of main.cu:289-413 for the black-disk inelastic probability alone (MODE 4 kernel).
+extern "C" int mcmc_run_inel_scan(mcmc_handle h, float *b_out, double *p_inel, double *p_inel_stderr, float dmax2)
+{
+    if (!h || !b_out || !p_inel) return set_error(MCMC_EINVAL, "null pointer");
+    const int R = h->cfg.totalRuns, nb = h->cfg.ndbs;
+    if (R <= 0) return set_error(MCMC_EINVAL, "totalRuns must be > 0");
+    if (nb <= 0) return set_error(MCMC_EINVAL, "ndbs must be > 0");
+    if (h->cfg.samplesPerThread <= 0) return set_error(MCMC_EINVAL, "samplesPerThread must be > 0");
+    MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
+    int rc = ensure_scan_buffer(h, (size_t)nb * R * 2);
+    if (rc) return rc;
+    for (int dbs = 0; dbs < nb; dbs++) {
+        const float b = h->cfg.b0 + dbs * h->cfg.db; // main.cu:328
+        for (int run = 0; run < R; run++) {
+            mcmc_xs_args a = xs_args(h, h->cfg.stepsize);
+            rc = mcmc_launch_integrate_inel(&a, (uint32_t)h->cfg.samplesPerThread, b, h->d_scan + ((size_t)dbs * R + run) * 2,
+                                            dmax2, h->stream);
+            if (rc) return rc;
+            h->sweeps_done += (uint64_t)h->cfg.samplesPerThread;
+        }
+    }
+    std::vector<double> m((size_t)nb * R * 2);
+    MCMC_HIP_CHECK(hipMemcpyAsync(m.data(), h->d_scan, sizeof(double) * m.size(), hipMemcpyDeviceToHost, h->stream));
+    MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<double> pr(R);
+    for (int dbs = 0; dbs < nb; dbs++) {
+        for (int run = 0; run < R; run++) {
+            const double *slot = &m[((size_t)dbs * R + run) * 2];
+            pr[run] = slot[1] > 0 ? slot[0] / slot[1] : 0.0;
+        }
+        const double avg = mcmc_Average_f64(pr.data(), R);
+        b_out[dbs] = h->cfg.b0 + dbs * h->cfg.db;
+        p_inel[dbs] = avg;
+        if (p_inel_stderr) p_inel_stderr[dbs] = R > 1 ? std::sqrt(mcmc_Variance_f64(pr.data(), R) / R) : 0.0;
+    }
+    return MCMC_OK;
+}
+
 extern "C" int mcmc_get_state(mcmc_handle h, float *host_out)
 {
     if (!h || !host_out) return set_error(MCMC_EINVAL, "null pointer");

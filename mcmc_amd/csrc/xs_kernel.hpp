@@ -263,12 +263,57 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
     }
 }
 
-// MODE bit 0: the S_AB product; bit 1: black-disk hit counters.
+// Black-disk "does this event collide at all" test (MODE 4): only the running minimum of d^2 is kept
+// (2 sub, mul, fma, half a v_min3 per pair; no exp, no counters, no participant marks).  The loop over
+// the lane's A nucleons has a wave-uniform trip count (absent nucleons sit at -1e30), so that with one
+// event per wavefront (G == 64) the first collision found anywhere in the wave ends the event's scan:
+// returns true as soon as `ballot(dmin < hit_d2)` is non-zero.  For central heavy-ion events that is the
+// first iteration.
+template <int JC, int G, int MATH>
+__device__ __forceinline__ bool sab_pairs_inel(const XsParams &p, const float2 *trE, uint32_t la, uint32_t lb, uint32_t GA,
+                                               uint32_t GB, uint32_t q0, float &dmin)
+{
+    float bx[JC], by[JC];
+#pragma unroll
+    for (int q = 0; q < JC; ++q) {
+        const uint32_t j = lb + (q0 + q) * GB;
+        const bool ok = j < p.nB;
+        const float2 v = trE[p.nA + (ok ? j : 0)];
+        bx[q] = ok ? v.x : 1.0e30f;
+        by[q] = ok ? v.y : 0.0f;
+    }
+    const uint32_t KA = (p.nA + GA - 1) >> p.ga_log2;
+    const bool ok0 = la < p.nA;
+    float2 a = trE[ok0 ? la : 0];
+    if (!ok0) a = make_float2(-1.0e30f, 0.0f);
+    for (uint32_t k = 0; k < KA; ++k) {
+        const uint32_t in = la + GA * (k + 1);
+        const bool more = in < p.nA;
+        float2 an = trE[more ? in : 0];
+        if (!more) an = make_float2(-1.0e30f, 0.0f);
+#pragma unroll
+        for (int q = 0; q < JC; ++q) {
+            const float dx = a.x - bx[q];
+            const float dy = a.y - by[q];
+            if constexpr (MATH == MCMC_MATH_FAST) dmin = __builtin_fminf(dmin, __builtin_fmaf(dy, dy, dx * dx));
+            else dmin = __builtin_fminf(dmin, dx * dx + dy * dy);
+        }
+        if constexpr (G == 64) {
+            if (__builtin_amdgcn_ballot_w64(dmin < p.hit_d2) != 0) return true;
+        }
+        a = an;
+    }
+    return false;
+}
+
+// MODE bit 0: the S_AB product; bit 1: black-disk hit counters; MODE 4: inelastic flag only.
 template <int G, int KIND, int RULE, int MATH, bool INJ, int MODE>
 __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
 {
     constexpr bool PROD = (MODE & 1) != 0;
     constexpr bool HITS = (MODE & 2) != 0;
+    constexpr bool INEL = (MODE & 4) != 0;
+    static_assert(!INEL || MODE == 4, "the inelastic-only mode stands alone");
     constexpr int EPB = XS_BLOCK / G; // events per block
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nN = p.nA + p.nB;
@@ -326,6 +371,26 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     const uint32_t JB = (p.nB + GB - 1) / GB;
 
     auto pair_sweep = [&](const float2 *trE) {
+        if constexpr (INEL) {
+            float dmin = __builtin_inff();
+            bool hit = false;
+            for (uint32_t q0 = 0; q0 < JB && !hit;) {
+                const uint32_t rem = JB - q0;
+                if (rem >= 16) {
+                    hit = sab_pairs_inel<16, G, MATH>(p, trE, la, lb, GA, GB, q0, dmin);
+                    q0 += 16;
+                } else if (rem >= 4) {
+                    hit = sab_pairs_inel<4, G, MATH>(p, trE, la, lb, GA, GB, q0, dmin);
+                    q0 += 4;
+                } else {
+                    hit = sab_pairs_inel<1, G, MATH>(p, trE, la, lb, GA, GB, q0, dmin);
+                    q0 += 1;
+                }
+            }
+            if constexpr (G != 64) hit = group_sum_u32<G>(dmin < p.hit_d2 ? 1u : 0u) != 0u;
+            h_inel += hit ? 1u : 0u;
+            return;
+        }
         float prod = 1.0f;
         uint32_t ncoll = 0;
         for (uint32_t q0 = 0; q0 < JB;) {
@@ -440,6 +505,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         if (valid) p.prevSample[(uint64_t)n * p.T + e] = stE[n].x;
     if (valid && lg == 0) {
         if constexpr (PROD) p.result[e] = (sum - err) / p.samples; // IntegrateSAB.cuh:88
+        if constexpr (INEL) p.hits[e] = h_inel;
         if constexpr (HITS) {
             p.hits[e] = h_coll;
             p.hits[p.T + e] = h_inel;

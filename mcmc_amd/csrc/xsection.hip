@@ -295,6 +295,41 @@ extern "C" int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuf
     return MCMC_OK;
 }
 
+extern "C" int mcmc_launch_integrate_inel(const mcmc_xs_args *a, uint32_t samples, float impactParameter, double *hits2,
+                                          float dmax2, void *stream)
+{
+    int rc = check_xs(a);
+    if (rc) return rc;
+    if (!hits2) return set_error(MCMC_EINVAL, "hits2 is null");
+    if (samples == 0) return set_error(MCMC_EINVAL, "samples must be > 0");
+    if (!(dmax2 > 0.0f)) return set_error(MCMC_EINVAL, "dmax2 must be > 0");
+    if (a->nNucleonsA == 0 || a->nNucleonsB == 0) return set_error(MCMC_EINVAL, "both nuclei need at least one nucleon");
+    const uint32_t nN = a->nNucleonsA + a->nNucleonsB;
+    if (a->injected && a->injected_stride < (uint64_t)samples * nN * 4)
+        return set_error(MCMC_EINVAL, "injected_stride too small for samples * nNucleons * 4 draws");
+    if (!(a->beta > 0.0f)) return set_error(MCMC_EINVAL, "beta must be > 0");
+    if (!a->workspace || a->workspace_bytes < mcmc_xs_workspace_bytes(a))
+        return set_error(MCMC_ENOMEM, "workspace smaller than mcmc_xs_workspace_bytes()");
+    hipStream_t s = (hipStream_t)stream;
+
+    XsParams p = make_params(a, samples);
+    if (a->math_mode == MCMC_MATH_FAST) p.pos_scale = sqrtf(1.4426950408889634f / (2.0f * a->beta));
+    p.b_stored = impactParameter * p.pos_scale;
+    p.hit_d2 = dmax2 * p.pos_scale * p.pos_scale;
+    uint32_t *hitbuf = (uint32_t *)((char *)a->workspace + rowmean_bytes(nN < 4 ? 4 : nN));
+    p.hits = hitbuf;
+    const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB, false);
+    if (plan.lds > 160 * 1024) return set_error(MCMC_EINVAL, "nuclei too large for the LDS-resident S_AB kernel (A+B <= ~1600)");
+    p.ga_log2 = (uint32_t)plan.ga_log2;
+    rc = launch_sab_mode<4>(a, p, plan, a->uniform_kind == MCMC_TARGET_R2WS, s);
+    if (rc) return rc;
+    rc = row_reduce<uint32_t>(hitbuf, 1, a->totalThreads, 1.0, hits2, 0, a->workspace, a->workspace_bytes, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(set_double_kernel, dim3(1), dim3(1), 0, s, hits2 + 1, (double)a->totalThreads * (double)samples);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
 extern "C" int mcmc_launch_row_mean_f32(const float *x, uint32_t rows, uint64_t cols, double *out, void *workspace,
                                         size_t workspace_bytes, void *stream)
 {

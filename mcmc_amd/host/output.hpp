@@ -63,4 +63,19 @@ inline bool write_sab_csv(const std::vector<float> &b, const std::vector<float> 
     return (bool)f;
 }
 
+// Black-disk scan: columns b, p_inel, p_inel_stderr (no counterpart in the reference's TTree).
+inline bool write_inel_csv(const std::vector<float> &b, const std::vector<double> &p, const std::vector<double> &e,
+                           const std::string &path)
+{
+    std::ofstream f(path);
+    if (!f) return false;
+    f << "b,p_inel,p_inel_stderr\n";
+    char line[160];
+    for (size_t i = 0; i < b.size(); ++i) {
+        std::snprintf(line, sizeof line, "%.9g,%.12g,%.6g\n", b[i], p[i], e[i]);
+        f << line;
+    }
+    return (bool)f;
+}
+
 } // namespace mcmc_host

@@ -56,7 +56,7 @@ int main(int argc, char **argv)
     mcmc_config cfg;
     mcmc_config_default(&cfg); // the constants of main.cu:38-82
     std::string outDir = "./", outFile = "out"; // main.cu:73-74 ("../data/", "out.root")
-    bool integrateRMS = true, integrateSAB = true, blackDisk = false; // main.cu:81-82
+    bool integrateRMS = true, integrateSAB = true, blackDisk = false, inelOnly = false; // main.cu:81-82
 
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -68,7 +68,7 @@ int main(int argc, char **argv)
             }
             std::puts("usage: xsection [name=value ...]   names: nNeutronA nProtonA nNeutronB nProtonB isotopeA isotopeB pdf pdfA\n"
                       "       pdfB totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix b0 db ndbs seed stepsize\n"
-                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk math device");
+                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk inelOnly math device");
             return a == "--help" || a == "-h" ? 0 : 2;
         }
         const std::string k = a.substr(0, eq), v = a.substr(eq + 1);
@@ -110,6 +110,7 @@ int main(int argc, char **argv)
         else if (k == "integrateRMS") integrateRMS = iv != 0;
         else if (k == "integrateSAB") integrateSAB = iv != 0;
         else if (k == "blackDisk") blackDisk = iv != 0;
+        else if (k == "inelOnly") inelOnly = iv != 0;
         else {
             std::fprintf(stderr, "xsection: unknown parameter '%s'\n", k.c_str());
             return 2;
@@ -154,7 +155,30 @@ int main(int argc, char **argv)
         }
     }
 
-    if (integrateSAB) { // main.cu:289-413
+    if (integrateSAB && inelOnly) { // the b loop of main.cu:289-413 for the black-disk inelastic probability alone
+        const int n = cfg.ndbs;
+        std::vector<float> b(n);
+        std::vector<double> pin(n), perr(n);
+        const float dmax2 = cfg.sigmaNN / 3.14159265358979f;
+        t0 = now();
+        if (mcmc_run_inel_scan(h, b.data(), pin.data(), perr.data(), dmax2)) die("mcmc_run_inel_scan");
+        const double t = ms(t0, now());
+        std::printf("inelastic scan: %d impact parameters in %.1f ms (%.3g event samples/s)\n", n, t, totalSamples * n / (t * 1e-3));
+        if (!mcmc_host::write_inel_csv(b, pin, perr, outDir + outFile + ".inel.csv")) {
+            std::fprintf(stderr, "xsection: cannot write %s%s.inel.csv\n", outDir.c_str(), outFile.c_str());
+            return 1;
+        }
+        if (n >= 2) { // sigma_inel = 2 pi int b p_inel(b) db (trapezoid), x10: fm^2 -> mb; errors added in quadrature
+            double s = 0, v = 0;
+            for (int i = 0; i < n; ++i) {
+                const double w = 0.5 * ((i > 0 ? b[i] - b[i - 1] : 0.0) + (i + 1 < n ? b[i + 1] - b[i] : 0.0)) * b[i];
+                s += w * pin[i];
+                v += w * w * perr[i] * perr[i];
+            }
+            const double k = 10 * 2 * 3.14159265358979323846;
+            std::printf("sigma_inel (black disk) = %.3f +/- %.3f mb\n", k * s, k * std::sqrt(v));
+        }
+    } else if (integrateSAB) { // main.cu:289-413
         const int n = cfg.ndbs;
         std::vector<float> b(n), S(n), E(n);
         std::vector<double> pin(n);

@@ -98,3 +98,21 @@ def test_xsection_driver_isotopes(dev, tmp_path):
     sab = np.genfromtxt(tmp_path / "pb.S_AB.csv", delimiter=",", names=True)
     assert sab["p_inel"][0] == 1.0 and sab["p_inel"][-1] < 0.01   # b = 0 always interacts, b = 20 fm never
     assert sab["S_AB"][0] < 1e-6 and sab["S_AB"][-1] > 0.99
+
+
+@pytest.mark.gpu
+def test_xsection_driver_inel_only(dev, tmp_path):
+    """inelOnly=1: the black-disk scan alone (mcmc_run_inel_scan) gives the same p_inel column as the full scan
+    with blackDisk=1 (same seed, same events) and prints sigma_inel with its statistical error."""
+    common = ["isotopeA=PB-208", "isotopeB=PB-208", "pdf=r2ws:6.62:0.546", "sigmaNN=6.76", "totalBlocks=8",
+              "threadsPerBlock=128", "samplesPerThread=8", "totalRuns=2", "samplesForMix=600", "integrateRMS=0",
+              "b0=0", "db=4", "ndbs=6", f"outDir={tmp_path}"]
+    r1 = subprocess.run([XSECTION, *common, "inelOnly=1", "outFile=i"], capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stderr + r1.stdout
+    r2 = subprocess.run([XSECTION, *common, "blackDisk=1", "outFile=f"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr + r2.stdout
+    a = np.genfromtxt(tmp_path / "i.inel.csv", delimiter=",", names=True)
+    f = np.genfromtxt(tmp_path / "f.S_AB.csv", delimiter=",", names=True)
+    assert a.dtype.names == ("b", "p_inel", "p_inel_stderr")
+    np.testing.assert_allclose(a["p_inel"], f["p_inel"], rtol=0, atol=1e-9)
+    assert "sigma_inel (black disk) =" in r1.stdout and "+/-" in r1.stdout.split("sigma_inel")[1]

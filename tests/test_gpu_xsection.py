@@ -194,3 +194,99 @@ def test_layer_b_sab_scan_and_cross_sections(dev):
         assert 200 < cs["rxn"][0] < 2000
     finally:
         L.check(L.lib.mcmc_destroy(h))
+
+
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast"])
+@pytest.mark.parametrize("nA,nB", [(2, 2), (3, 5), (16, 20), (70, 70)])
+@pytest.mark.parametrize("b", [0.0, 3.0])
+def test_inel_injected(dev, oracle, mode, nA, nB, b):
+    """Inelastic-flag-only kernel (mcmc_launch_integrate_inel): the count of samples with >= 1 black-disk
+    collision equals the oracle's, the chains advance exactly as in MCIntegrate_S_AB, and the count is identical
+    to hits[1] of the full-counter kernel on the same draws."""
+    nN = nA + nB
+    T = 37 if nN < 60 else 9
+    samples, step = (17 if nN < 60 else 6), 2.2
+    targets = [WS20] * nN
+    rng = np.random.default_rng(nA * 100 + nB + 7)
+    d = np.empty((T, samples * nN * 4), dtype=np.float32)
+    blk = d.reshape(T, samples, 2, nN, 2)
+    blk[:, :, 0, :, 0] = rng.standard_normal((T, samples, nN))
+    blk[:, :, 0, :, 1] = 1.0 - rng.random((T, samples, nN))
+    blk[:, :, 1, :, :] = 1.0 - rng.random((T, samples, nN, 2))
+    dmax2 = 4.3 / np.pi
+    dj = torch.from_numpy(d).to(dev)
+    xs = _xs(dev, nA, nB, T, targets, mode)
+    inel = xs.MCIntegrate_Inel(samples, b, dmax2, stepsize=step, injected=dj).clone()
+    full = _xs(dev, nA, nB, T, targets, mode)
+    _, _, hits = full.MCIntegrate_S_AB(samples, b, stepsize=step, injected=dj, dmax2=dmax2)
+    torch.cuda.synchronize()
+    inel, hits = inel.cpu().numpy(), hits.cpu().numpy()
+    assert inel[1] == T * samples
+    assert inel[0] == hits[1]
+    assert torch.equal(xs.prevSample, full.prevSample)
+    tot, all_ok = 0, True
+    for e in range(T):
+        mh = d[e].reshape(samples, 2, nN, 2)[:, 0].reshape(samples, nN * 2)
+        _, _, _, margin = oracle.warmup_thread_trace(targets, [1.0] * nN, step, samples, mh)
+        _, _, h, _ = oracle.integrate_sab_thread(nA, nB, targets, [1.0] * nN, step, samples, b, d[e], dmax2=dmax2)
+        tot += h[1]
+        all_ok = all_ok and margin > 1e-5
+    if all_ok:
+        assert abs(inel[0] - tot) <= 1
+    else:
+        assert abs(inel[0] - tot) <= 0.2 * T * samples
+
+
+@pytest.mark.parametrize("b", [0.0, 13.0, 17.0])
+def test_inel_heavy_ion_equals_full_counters(dev, b):
+    """Pb-208 + Pb-208 (one event per wavefront, early exit at the first collision): Philox mode, central,
+    peripheral and beyond-contact impact parameters; the flag count equals hits[1] of the full-counter kernel
+    and the chain state is bit-identical."""
+    from mcmc_amd import lib as L
+    nA = nB = 208
+    PB = (O.R2WS, 6.62, 0.546)
+    T, samples = 24, 8
+    kw = dict(seed=4242, event_offset=1000)
+    xs = _xs(dev, nA, nB, T, [PB] * (nA + nB), "nodiv_fast", **kw)
+    full = _xs(dev, nA, nB, T, [PB] * (nA + nB), "nodiv_fast", **kw)
+    for eng in (xs, full):
+        eng.WarmupMetropolis(300, stepsize=2.2)
+    dmax2 = 6.76 / np.pi
+    inel = xs.MCIntegrate_Inel(samples, b, dmax2).clone()
+    _, _, hits = full.MCIntegrate_S_AB(samples, b, dmax2=dmax2)
+    torch.cuda.synchronize()
+    inel, hits = inel.cpu().numpy(), hits.cpu().numpy()
+    assert inel[1] == T * samples and inel[0] == hits[1]
+    assert torch.equal(xs.prevSample, full.prevSample)
+    if b == 0.0:
+        assert inel[0] == T * samples
+    if b == 17.0:
+        assert inel[0] < 0.5 * T * samples
+
+
+def test_layer_b_inel_scan(dev):
+    """mcmc_run_inel_scan == the p_inel column of mcmc_run_sab_scan on a handle with the same seed."""
+    from mcmc_amd import lib as L
+    out = []
+    for which in ("inel", "sab"):
+        cfg = L.Config()
+        L.lib.mcmc_config_default(C.byref(cfg))
+        cfg.totalBlocks, cfg.threadsPerBlock, cfg.samplesPerThread, cfg.totalRuns = 8, 128, 32, 3
+        cfg.ndbs, cfg.db = 12, 0.6
+        h = C.c_void_p()
+        L.check(L.lib.mcmc_create(C.byref(cfg), C.byref(h)))
+        try:
+            L.check(L.lib.mcmc_warmup(h, 2.2, 128))
+            n = cfg.ndbs
+            b, pin, perr = (C.c_float * n)(), (C.c_double * n)(), (C.c_double * n)()
+            if which == "inel":
+                L.check(L.lib.mcmc_run_inel_scan(h, b, pin, perr, 4.3 / np.pi))
+                assert all(e >= 0 for e in perr[:]) and max(perr[:]) > 0
+            else:
+                S, E = (C.c_float * n)(), (C.c_float * n)()
+                L.check(L.lib.mcmc_run_sab_scan(h, b, S, E, pin, 4.3 / np.pi))
+            out.append(np.array(pin[:]))
+        finally:
+            L.check(L.lib.mcmc_destroy(h))
+    np.testing.assert_allclose(out[0], out[1], rtol=0, atol=1e-12)
+    assert out[0][0] > 0.8 and out[0][-1] < 0.1

@@ -72,6 +72,12 @@ def main():
         print(json.dumps({"kernel": "MCIntegrate_S_AB+hits", "system": "Pb-208+Pb-208", "b": 7.0, "events": T,
                           "samples": args.samples, "ms": ms, "event_samples_per_s": n / (ms * 1e-3),
                           "pairs_per_s": n * 208 * 208 / (ms * 1e-3), "hits": xs.hits.cpu().tolist()}))
+        for b in (0.0, 7.0, 14.0, 18.0):
+            ms = timed(lambda: xs.MCIntegrate_Inel(args.samples, b, 6.76 / 3.14159265, stepsize=2.2), args.reps)
+            h = xs.hits.cpu().tolist()
+            print(json.dumps({"kernel": "MCIntegrate_Inel", "system": "Pb-208+Pb-208", "b": b, "events": T,
+                              "samples": args.samples, "ms": ms, "event_samples_per_s": n / (ms * 1e-3),
+                              "p_inel": h[0] / h[1]}))
     if "he" in which:
         T = 1 << 20
         xs = api.XsEngine(4, 4, T, [HE] * 8, accept_rule=rule, math_mode=L.MATH_FAST, device=dev)
