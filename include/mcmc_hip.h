@@ -332,6 +332,16 @@ int mcmc_stepsize_run(const mcmc_target *target, int precision, int accept_rule,
                       uint64_t seed, double x0, mcmc_chain_summary *summary /* [n_coords] */,
                       double *rho /* [n_coords][n_lags] or NULL */, void *samples_host /* or NULL */);
 
+/* The step-size study (stepsize/src/main.cpp:14-36; efficiency 1/(1 + 2 sum rho_k) of
+ * StepSizeAnalysis.ipynb cell 1) on the device: n_widths equally spaced widths in
+ * [lo, hi], n_chains chains of n_warmup + n_steps steps each (FP32, 49 lags); out
+ * arrays [n_widths] (any may be NULL); *best_width = width of least integrated
+ * autocorrelation time (parabola through the grid minimum).  Use it for the width
+ * that main.cu:149,197,335 hard-codes as 2.2f.                                   */
+int mcmc_tune_stepsize(const mcmc_target *target, double lo, double hi, int n_widths, uint64_t n_chains,
+                       uint64_t n_warmup, uint64_t n_steps, uint64_t seed, double x0, double *widths,
+                       double *acceptance, double *tau_int, double *best_width);
+
 /* Isotope name ("PB-208", "208-pb") -> Z and A: NuclearZAndA, xsection/tools/MCMCMacro.py:63-83
  * (used by IntegrationSettings.SetIsotopeA/B, :145-157: protons = Z, neutrons = A - Z). */
 int mcmc_isotope(const char *name, int *Z, int *A);

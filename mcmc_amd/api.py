@@ -113,6 +113,15 @@ def MetropolisHastingsAlgorithm(iterations, stepSize, target=None, n_chains=1, p
     return s.acceptance, (samples[:, 0, :] if samples is not None else None), info
 
 
+def TuneStepSize(target, lo, hi, n_widths=9, n_chains=1 << 16, n_warmup=1000, n_steps=2000, seed=314159265, x0=1.0):
+    """`mcmc_tune_stepsize`: the stepsize executable's study on the device -> (best_width, widths, acceptance, tau_int)."""
+    w, a, t = (C.c_double * n_widths)(), (C.c_double * n_widths)(), (C.c_double * n_widths)()
+    best = C.c_double()
+    L.check(_lib.mcmc_tune_stepsize(C.byref(target), float(lo), float(hi), int(n_widths), int(n_chains), int(n_warmup),
+                                    int(n_steps), int(seed), float(x0), w, a, t, C.byref(best)))
+    return best.value, np.array(w[:]), np.array(a[:]), np.array(t[:])
+
+
 class XsEngine:
     """xsection Layer A on torch buffers: prevSample[nN][T], per-nucleon targets,
     result buffers and workspace; methods mirror the reference kernels."""

@@ -603,3 +603,42 @@ done:
     if (d_samples) (void)hipFree(d_samples);
     return rc;
 }
+
+// The step-size study of the stepsize executable (stepsize/src/main.cpp:14-36: acceptance and lag-k
+// autocorrelation per proposal width) run on the device for a grid of widths, and the width of least
+// integrated autocorrelation time 1 + 2 sum_k rho_k (the notebook's efficiency, StepSizeAnalysis.ipynb
+// cell 1), refined by a parabola through the grid minimum and its neighbours.  Closes the loop to
+// xsection, whose width is the constant 2.2f of main.cu:149,197,335.
+extern "C" int mcmc_tune_stepsize(const mcmc_target *target, double lo, double hi, int n_widths, uint64_t n_chains,
+                                  uint64_t n_warmup, uint64_t n_steps, uint64_t seed, double x0, double *widths,
+                                  double *acceptance, double *tau_int, double *best_width)
+{
+    if (!target || !best_width) return set_error(MCMC_EINVAL, "null pointer");
+    if (!(lo > 0.0) || !(hi > lo) || n_widths < 3) return set_error(MCMC_EINVAL, "need 0 < lo < hi and n_widths >= 3");
+    if (n_steps <= (uint64_t)MCMC_MAX_LAGS + 1) return set_error(MCMC_EINVAL, "n_steps must exceed MCMC_MAX_LAGS + 1");
+    std::vector<double> w(n_widths), acc(n_widths), tau(n_widths);
+    for (int i = 0; i < n_widths; ++i) {
+        w[i] = lo + (hi - lo) * i / (n_widths - 1);
+        mcmc_chain_summary s;
+        const int rc = mcmc_stepsize_run(target, 32, MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, w[i], n_chains, 1, n_warmup, n_steps,
+                                         MCMC_MAX_LAGS, seed, x0, &s, nullptr, nullptr);
+        if (rc) return rc;
+        acc[i] = s.acceptance;
+        tau[i] = s.tau_int;
+    }
+    int k = 0;
+    for (int i = 1; i < n_widths; ++i)
+        if (tau[i] < tau[k]) k = i;
+    double best = w[k];
+    if (k > 0 && k + 1 < n_widths) { // vertex of the parabola through (w[k-1..k+1], tau[k-1..k+1]); equal spacing
+        const double d = tau[k - 1] - 2.0 * tau[k] + tau[k + 1];
+        if (d > 0.0) best = w[k] + 0.5 * (w[k] - w[k - 1]) * (tau[k - 1] - tau[k + 1]) / d;
+    }
+    for (int i = 0; i < n_widths; ++i) {
+        if (widths) widths[i] = w[i];
+        if (acceptance) acceptance[i] = acc[i];
+        if (tau_int) tau_int[i] = tau[i];
+    }
+    *best_width = best;
+    return MCMC_OK;
+}

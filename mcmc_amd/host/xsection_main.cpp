@@ -57,6 +57,7 @@ int main(int argc, char **argv)
     mcmc_config_default(&cfg); // the constants of main.cu:38-82
     std::string outDir = "./", outFile = "out"; // main.cu:73-74 ("../data/", "out.root")
     bool integrateRMS = true, integrateSAB = true, blackDisk = false, inelOnly = false; // main.cu:81-82
+    bool autoStep = false;
 
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -100,7 +101,10 @@ int main(int argc, char **argv)
         else if (k == "db") cfg.db = fv;
         else if (k == "ndbs") cfg.ndbs = iv;
         else if (k == "seed") cfg.seed = std::strtoull(v.c_str(), nullptr, 10);
-        else if (k == "stepsize") cfg.stepsize = fv;
+        else if (k == "stepsize") { // a number, or "auto": tuned on the device (mcmc_tune_stepsize)
+            autoStep = v == "auto";
+            if (!autoStep) cfg.stepsize = fv;
+        }
         else if (k == "sigmaNN") cfg.sigmaNN = fv;
         else if (k == "beta") cfg.beta = fv;
         else if (k == "device") cfg.device = iv;
@@ -132,6 +136,17 @@ int main(int argc, char **argv)
                 "parameters, %.3g samples (log10 %.2f)\n",
                 totalThreads, cfg.samplesPerThread, cfg.totalRuns, totalSamples, std::log10(totalSamples), cfg.ndbs,
                 totalSamples * cfg.ndbs, std::log10(totalSamples * cfg.ndbs));
+
+    if (autoStep) { // the stepsize study for nucleus A's neutron density; widths from 0.25 to 2 radii
+        const mcmc_target &t = cfg.neutronA;
+        const double scale = t.kind == MCMC_TARGET_WS || t.kind == MCMC_TARGET_R2WS ? t.p0 + 2.0 * t.p1 : std::sqrt((double)t.p0);
+        double best = 0.0;
+        if (mcmc_tune_stepsize(&t, 0.25 * scale, 2.0 * scale, 15, 1 << 16, 2000, 2000, cfg.seed, cfg.initSample, nullptr, nullptr,
+                               nullptr, &best))
+            die("mcmc_tune_stepsize");
+        cfg.stepsize = (float)best;
+        std::printf("proposal width tuned on the device: %.3f (reference constant: 2.2)\n", best);
+    }
 
     mcmc_handle h = nullptr;
     if (mcmc_create(&cfg, &h)) die("mcmc_create");

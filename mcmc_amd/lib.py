@@ -90,7 +90,7 @@ EXPORTS = [
     "mcmc_Average_f64", "mcmc_Variance_f64", "mcmc_AutoCorrelation_f64", "mcmc_cross_sections",
     "mcmc_config_default", "mcmc_create", "mcmc_destroy", "mcmc_warmup", "mcmc_integrate_r2",
     "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_run_inel_scan", "mcmc_get_state", "mcmc_wait",
-    "mcmc_stepsize_run", "mcmc_isotope", "mcmc_last_error", "mcmc_version", "mcmc_device_count",
+    "mcmc_stepsize_run", "mcmc_tune_stepsize", "mcmc_isotope", "mcmc_last_error", "mcmc_version", "mcmc_device_count",
 ]
 
 
@@ -156,6 +156,8 @@ def _load():
                                       C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, P(ChainSummary),
                                       P(C.c_double), C.c_void_p]
     lib.mcmc_isotope.argtypes = [C.c_char_p, P(C.c_int), P(C.c_int)]
+    lib.mcmc_tune_stepsize.argtypes = [P(Target), C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
+                                       C.c_uint64, C.c_double, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double)]
     lib.mcmc_last_error.restype = C.c_char_p
     lib.mcmc_version.restype = C.c_char_p
     lib.mcmc_device_count.restype = C.c_int

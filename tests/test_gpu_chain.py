@@ -219,3 +219,16 @@ def test_argument_errors(dev):
     eng.args.workspace_bytes = 0
     with pytest.raises(L.McmcError):
         eng.run(50)
+
+
+def test_tune_stepsize_reproduces_reference_optimum(dev):
+    """mcmc_tune_stepsize on r^2 WS(2.0, 0.54): the reference's own study has its efficiency optimum at width 2.48
+    (stepsize/results/r2WS_2.0_0.54.png, StepSizeAnalysis.ipynb); acceptance falls monotonically with the width."""
+    from mcmc_amd import api, lib as L
+    best, w, acc, tau = api.TuneStepSize(api.make_target(L.TARGET_R2WS, 2.0, 0.54), 1.0, 4.0, n_widths=13,
+                                         n_chains=1 << 15, n_warmup=500, n_steps=1500)
+    assert 2.2 < best < 2.8
+    assert np.all(np.diff(acc) < 0) and np.all(tau >= 1.0)
+    assert tau.min() < tau[0] and tau.min() < tau[-1]
+    with pytest.raises(L.McmcError):
+        api.TuneStepSize(api.make_target(L.TARGET_R2WS, 2.0, 0.54), 2.0, 1.0)
