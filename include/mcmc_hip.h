@@ -225,6 +225,14 @@ size_t mcmc_xs_workspace_bytes(const mcmc_xs_args *a);
 int mcmc_launch_init_sample_array(float *prevSample, float initSample, uint32_t nNucleons, uint64_t totalThreads,
                                   void *stream);
 
+/* Randomised chain starts -- what main.cu:144-148 describes but does not do
+ * ("randomize the initial states of the chain ... treating it as a discrete
+ * pdf, and sampling according to that"): prevSample[n][t] is drawn from nucleon
+ * n's density tabulated on 1024 bins (inverse CDF, one Philox uniform of stream
+ * tag 4 per chain; uses targets, prevSample, totalThreads, seed, event_offset
+ * of `a`).  A short warm-up afterwards removes the tabulation error.          */
+int mcmc_launch_init_sample_from_pdf(const mcmc_xs_args *a, void *stream);
+
 /* WarmupMetropolis, Metropolis.cuh:83-108 (main.cu:149). */
 int mcmc_launch_warmup_metropolis(const mcmc_xs_args *a, uint32_t iterations, void *stream);
 
@@ -302,6 +310,7 @@ void mcmc_config_default(mcmc_config *cfg);   /* the constants of main.cu:38-82 
 int mcmc_create(const mcmc_config *cfg, mcmc_handle *out);   /* cudaMalloc + RandStateInit + InitSampleArray, main.cu:123-134 */
 int mcmc_destroy(mcmc_handle h);                              /* main.cu:419-422 */
 int mcmc_warmup(mcmc_handle h, float stepsize, int iterations);   /* main.cu:149-152 */
+int mcmc_init_from_pdf(mcmc_handle h);   /* randomised starts (main.cu:144-148), see mcmc_launch_init_sample_from_pdf */
 /* One run of MCIntegrate_R2 over all threads: out_run_mean[nNucleons] (main.cu:197-223). */
 int mcmc_integrate_r2(mcmc_handle h, float stepsize, int samples, float *out_run_mean);
 /* One run of MCIntegrate_S_AB at impact parameter b (main.cu:335-359); hits may be NULL. */

@@ -165,6 +165,10 @@ class XsEngine:
     def InitSampleArray(self, initSample):
         L.check(_lib.mcmc_launch_init_sample_array(_p(self.prevSample), float(initSample), self.nN, self.T, _stream()))
 
+    def InitSampleFromPdf(self):
+        """Randomised starts drawn from each nucleon's tabulated density (main.cu:144-148's suggestion)."""
+        L.check(_lib.mcmc_launch_init_sample_from_pdf(C.byref(self.args), _stream()))
+
     def WarmupMetropolis(self, iterations, stepsize=None, injected=None):
         if stepsize is not None:
             self.args.stepsize = float(stepsize)

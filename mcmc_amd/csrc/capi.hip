@@ -359,6 +359,14 @@ extern "C" int mcmc_warmup(mcmc_handle h, float stepsize, int iterations)
     return MCMC_OK;
 }
 
+extern "C" int mcmc_init_from_pdf(mcmc_handle h)
+{
+    if (!h) return set_error(MCMC_EINVAL, "null handle");
+    MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
+    mcmc_xs_args a = xs_args(h, h->cfg.stepsize);
+    return mcmc_launch_init_sample_from_pdf(&a, h->stream);
+}
+
 extern "C" int mcmc_integrate_r2(mcmc_handle h, float stepsize, int samples, float *out_run_mean)
 {
     if (!h || !out_run_mean) return set_error(MCMC_EINVAL, "null pointer");

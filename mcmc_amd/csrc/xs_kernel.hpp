@@ -47,6 +47,78 @@ __global__ void init_sample_kernel(float *prevSample, float v, uint64_t total)
 }
 
 // ---------------------------------------------------------------------
+// Randomised chain starts.  The reference starts every chain at 1.0f and notes that it would be
+// better to "randomize the initial states of the chain ... by treating it as a discrete pdf, and
+// sampling according to that" (main.cu:144-148).  This is that: the nucleon's density tabulated on
+// INIT_BINS equal bins of [0, r_max], inverse CDF with one Philox uniform (tag 4), linear inside
+// the bin.  grid = (tiles, nN); every block rebuilds its nucleon's table (4 density values per thread).
+constexpr int INIT_BINS = 1024;
+constexpr uint32_t TAG_INIT = 4u;
+
+__device__ __forceinline__ float pdf_any(const Target<float> &t, float r)
+{
+    switch (t.kind) {
+    case MCMC_TARGET_WS: return pdf_precise<MCMC_TARGET_WS>(t, r);
+    case MCMC_TARGET_R2WS: return pdf_precise<MCMC_TARGET_R2WS>(t, r);
+    case MCMC_TARGET_GAUSS: return pdf_precise<MCMC_TARGET_GAUSS>(t, r);
+    default: return pdf_precise<MCMC_TARGET_R2GAUSS>(t, r);
+    }
+}
+
+// upper end of the table: the density is below ~1e-7 of its bulk value beyond it
+__host__ __device__ inline float init_r_max(const mcmc_target &t)
+{
+    if (t.kind == MCMC_TARGET_WS || t.kind == MCMC_TARGET_R2WS) return t.p0 + 20.0f * t.p1;
+    return 7.0f * sqrtf(t.p0);
+}
+
+__global__ __launch_bounds__(XS_BLOCK) void init_from_pdf_kernel(const mcmc_target *targets, float *prevSample, uint64_t T,
+                                                                 uint64_t seed, uint64_t event_offset)
+{
+    static_assert(INIT_BINS == 4 * XS_BLOCK, "four bins per thread");
+    __shared__ float cdf[INIT_BINS + 1];
+    __shared__ float part[XS_BLOCK];
+    const uint32_t n = blockIdx.y, tid = threadIdx.x;
+    const mcmc_target mt = targets[n];
+    const Target<float> tg = make_target<float>(mt);
+    const float h = init_r_max(mt) / INIT_BINS;
+    float w[4], run = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        run += pdf_any(tg, ((float)(tid * 4 + q) + 0.5f) * h);
+        w[q] = run;
+    }
+    part[tid] = run;
+    __syncthreads();
+    for (uint32_t off = 1; off < XS_BLOCK; off <<= 1) { // inclusive scan of the per-thread totals
+        const float v = tid >= off ? part[tid - off] : 0.0f;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const float base = tid ? part[tid - 1] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cdf[tid * 4 + q + 1] = base + w[q];
+    if (tid == 0) cdf[0] = 0.0f;
+    __syncthreads();
+    const float total = cdf[INIT_BINS];
+    for (uint64_t tile = blockIdx.x; tile * XS_BLOCK < T; tile += gridDim.x) {
+        const uint64_t e = tile * XS_BLOCK + tid;
+        if (e >= T) continue;
+        const float target = u01(draw_block(seed, event_offset + e, n, 0, TAG_INIT).x) * total;
+        uint32_t lo = 0, hi = INIT_BINS; // cdf[lo] <= target (< cdf[hi] unless the uniform rounded to 1)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cdf[mid] <= target) lo = mid;
+            else hi = mid;
+        }
+        const float den = cdf[lo + 1] - cdf[lo];
+        const float v = den > 0.0f ? __builtin_fminf((target - cdf[lo]) / den, 1.0f) : 0.5f;
+        prevSample[(uint64_t)n * T + e] = ((float)lo + v) * h;
+    }
+}
+
+// ---------------------------------------------------------------------
 // grid = (ceil(T/256), nN): blockIdx.y is the nucleon, so the target kind is
 // block-uniform and selected once outside the sweep loop.
 template <int KIND, int RULE, int MATH, bool INJ, bool R2>

@@ -210,6 +210,19 @@ extern "C" int mcmc_launch_init_sample_array(float *prevSample, float initSample
     return MCMC_OK;
 }
 
+extern "C" int mcmc_launch_init_sample_from_pdf(const mcmc_xs_args *a, void *stream)
+{
+    int rc = check_xs(a);
+    if (rc) return rc;
+    const uint32_t nN = a->nNucleonsA + a->nNucleonsB;
+    const uint64_t tiles = (a->totalThreads + XS_BLOCK - 1) / XS_BLOCK;
+    const dim3 grid((unsigned)(tiles < 1024 ? tiles : 1024), nN);
+    hipLaunchKernelGGL(init_from_pdf_kernel, grid, dim3(XS_BLOCK), 0, (hipStream_t)stream, a->targets, a->prevSample,
+                       a->totalThreads, a->seed, a->event_offset);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
 extern "C" int mcmc_launch_warmup_metropolis(const mcmc_xs_args *a, uint32_t iterations, void *stream)
 {
     int rc = check_xs(a);

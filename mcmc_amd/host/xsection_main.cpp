@@ -57,7 +57,7 @@ int main(int argc, char **argv)
     mcmc_config_default(&cfg); // the constants of main.cu:38-82
     std::string outDir = "./", outFile = "out"; // main.cu:73-74 ("../data/", "out.root")
     bool integrateRMS = true, integrateSAB = true, blackDisk = false, inelOnly = false; // main.cu:81-82
-    bool autoStep = false;
+    bool autoStep = false, randomStart = false;
 
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -69,7 +69,7 @@ int main(int argc, char **argv)
             }
             std::puts("usage: xsection [name=value ...]   names: nNeutronA nProtonA nNeutronB nProtonB isotopeA isotopeB pdf pdfA\n"
                       "       pdfB totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix b0 db ndbs seed stepsize\n"
-                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk inelOnly math device");
+                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk inelOnly randomStart math device");
             return a == "--help" || a == "-h" ? 0 : 2;
         }
         const std::string k = a.substr(0, eq), v = a.substr(eq + 1);
@@ -115,6 +115,7 @@ int main(int argc, char **argv)
         else if (k == "integrateSAB") integrateSAB = iv != 0;
         else if (k == "blackDisk") blackDisk = iv != 0;
         else if (k == "inelOnly") inelOnly = iv != 0;
+        else if (k == "randomStart") randomStart = iv != 0;
         else {
             std::fprintf(stderr, "xsection: unknown parameter '%s'\n", k.c_str());
             return 2;
@@ -153,6 +154,7 @@ int main(int argc, char **argv)
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 
+    if (randomStart && mcmc_init_from_pdf(h)) die("mcmc_init_from_pdf"); // main.cu:144-148
     auto t0 = now();
     if (mcmc_warmup(h, cfg.stepsize, cfg.samplesForMix)) die("mcmc_warmup"); // main.cu:149
     std::printf("Metropolis chain warm-up (%d sweeps): %.1f ms\n", cfg.samplesForMix, ms(t0, now()));

@@ -84,12 +84,12 @@ EXPORTS = [
     "mcmc_chain_workspace_bytes", "mcmc_chain_run", "mcmc_stats_finalize", "mcmc_launch_draws",
     "mcmc_mvn_workspace_bytes", "mcmc_mvn_run", "mcmc_mvn_finalize",
     "mcmc_xs_workspace_bytes", "mcmc_launch_init_sample_array", "mcmc_launch_warmup_metropolis",
-    "mcmc_launch_integrate_r2", "mcmc_launch_integrate_sab", "mcmc_launch_integrate_inel", "mcmc_launch_row_mean_f32",
+    "mcmc_launch_init_sample_from_pdf", "mcmc_launch_integrate_r2", "mcmc_launch_integrate_sab", "mcmc_launch_integrate_inel", "mcmc_launch_row_mean_f32",
     "mcmc_row_mean_workspace_bytes",
     "mcmc_Sum", "mcmc_Average", "mcmc_Variance", "mcmc_AutoCorrelation",
     "mcmc_Average_f64", "mcmc_Variance_f64", "mcmc_AutoCorrelation_f64", "mcmc_cross_sections",
     "mcmc_config_default", "mcmc_create", "mcmc_destroy", "mcmc_warmup", "mcmc_integrate_r2",
-    "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_run_inel_scan", "mcmc_get_state", "mcmc_wait",
+    "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_run_inel_scan", "mcmc_init_from_pdf", "mcmc_get_state", "mcmc_wait",
     "mcmc_stepsize_run", "mcmc_tune_stepsize", "mcmc_isotope", "mcmc_last_error", "mcmc_version", "mcmc_device_count",
 ]
 
@@ -121,6 +121,7 @@ def _load():
     lib.mcmc_launch_integrate_r2.argtypes = [P(XsArgs), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.mcmc_launch_integrate_sab.argtypes = [P(XsArgs), C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p,
                                               C.c_float, C.c_void_p]
+    lib.mcmc_launch_init_sample_from_pdf.argtypes = [P(XsArgs), C.c_void_p]
     lib.mcmc_launch_integrate_inel.argtypes = [P(XsArgs), C.c_uint32, C.c_float, C.c_void_p, C.c_float, C.c_void_p]
     lib.mcmc_launch_row_mean_f32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t,
                                              C.c_void_p]
@@ -149,6 +150,7 @@ def _load():
                                        C.c_float]
     lib.mcmc_run_rms.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float)]
     lib.mcmc_run_sab_scan.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_double), C.c_float]
+    lib.mcmc_init_from_pdf.argtypes = [C.c_void_p]
     lib.mcmc_run_inel_scan.argtypes = [C.c_void_p, P(C.c_float), P(C.c_double), P(C.c_double), C.c_float]
     lib.mcmc_get_state.argtypes = [C.c_void_p, P(C.c_float)]
     lib.mcmc_wait.argtypes = [C.c_void_p]

@@ -722,3 +722,33 @@ ORC_API uint64_t orc_baseline_chains_f32(uint64_t chain0, uint64_t n_chains, int
     if (sum2) *sum2 = s2;
     return acc;
 }
+
+/* ---------------------------------------------------------------------
+ * Randomised chain start (the improvement main.cu:144-148 describes; not implemented in the
+ * reference): the density tabulated at the midpoints of 1024 equal bins of [0, r_max], inverse CDF
+ * with the first word of Philox block (id, coord, blk 0, tag 4), linear inside the bin.  The table
+ * is summed sequentially in double here (the device scans it in float, in tree order), so the two
+ * agree to rounding of the table, not bit for bit.                           */
+ORC_API float orc_init_from_pdf(int kind, float p0, float p1, uint64_t seed, uint64_t id, uint32_t coord)
+{
+    enum { NB = 1024 };
+    static double cdf[NB + 1];
+    const float rmax = (kind == ORC_WS || kind == ORC_R2WS) ? p0 + 20.0f * p1 : 7.0f * sqrtf(p0);
+    const float h = rmax / NB;
+    uint32_t w[4];
+    int lo = 0, hi = NB, k;
+    double target, den, v;
+    cdf[0] = 0.0;
+    for (k = 0; k < NB; k++) cdf[k + 1] = cdf[k] + (double)orc_pdf_f32(kind, p0, p1, ((float)k + 0.5f) * h);
+    orc_block(seed, id, coord, 0u, 4u, w);
+    target = (double)orc_u01_f32(w[0]) * cdf[NB];
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) / 2;
+        if (cdf[mid] <= target) lo = mid;
+        else hi = mid;
+    }
+    den = cdf[lo + 1] - cdf[lo];
+    v = den > 0.0 ? (target - cdf[lo]) / den : 0.5;
+    if (v > 1.0) v = 1.0;
+    return (float)(((double)lo + v) * (double)h);
+}

@@ -224,6 +224,11 @@ class Oracle:
     def target_f32(self, kind, p0, p1, r):
         return self.lib.orc_target_f32(C.c_int(kind), C.c_float(p0), C.c_float(p1), C.c_float(r))
 
+    def init_from_pdf(self, kind, p0, p1, seed, chain, coord):
+        self.lib.orc_init_from_pdf.restype = C.c_float
+        return self.lib.orc_init_from_pdf(C.c_int(kind), C.c_float(p0), C.c_float(p1), C.c_uint64(seed), C.c_uint64(chain),
+                                          C.c_uint32(coord))
+
     def gamma_nn_r2(self, r, sigmaNN=4.3, beta=0.2):
         return self.lib.orc_GammaNNR2(C.c_float(r), C.c_float(sigmaNN), C.c_float(beta))
 

@@ -116,3 +116,16 @@ def test_xsection_driver_inel_only(dev, tmp_path):
     assert a.dtype.names == ("b", "p_inel", "p_inel_stderr")
     np.testing.assert_allclose(a["p_inel"], f["p_inel"], rtol=0, atol=1e-9)
     assert "sigma_inel (black disk) =" in r1.stdout and "+/-" in r1.stdout.split("sigma_inel")[1]
+
+
+@pytest.mark.gpu
+def test_xsection_driver_random_start(dev, tmp_path):
+    """randomStart=1 (chain starts drawn from the density, main.cu:144-148's suggestion): Pb-208 RMS is right after a
+    warm-up of 32 sweeps, which from the reference's start at 1.0 fm is far too short."""
+    common = ["isotopeA=PB-208", "nNeutronB=0", "nProtonB=0", "pdf=r2ws:6.62:0.546", "totalBlocks=32", "threadsPerBlock=128",
+              "samplesPerThread=64", "totalRuns=4", "samplesForMix=32", "integrateSAB=0", f"outDir={tmp_path}"]
+    r = subprocess.run([XSECTION, *common, "randomStart=1", "outFile=r"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    rms = np.genfromtxt(tmp_path / "r.RMS.csv", delimiter=",", names=True)
+    assert len(rms) == 208
+    assert abs(rms["RMS"].mean() - 5.514875) < 5e-3

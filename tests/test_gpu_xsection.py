@@ -290,3 +290,32 @@ def test_layer_b_inel_scan(dev):
             L.check(L.lib.mcmc_destroy(h))
     np.testing.assert_allclose(out[0], out[1], rtol=0, atol=1e-12)
     assert out[0][0] > 0.8 and out[0][-1] < 0.1
+
+
+def test_init_from_pdf_matches_oracle_and_is_stationary(dev, oracle):
+    """Randomised starts (main.cu:144-148's suggestion): the device's inverse-CDF draw equals the oracle's for the same
+    Philox word (to table rounding), the starts already have the target's <r^2> (quadrature 6.424247 for
+    r^2 WS(2.0, 0.54)), a short warm-up leaves it there, and the draw depends on the global event id only."""
+    T = 1 << 16
+    targets = [WS20, (O.R2WS, 6.62, 0.546), (O.R2GAUSS, 1.0, 0.0), (O.WS, 2.0, 0.54)]
+    xs = _xs(dev, 4, 0, T, targets, "recip_fast", seed=123, event_offset=500)
+    xs.InitSampleFromPdf()
+    torch.cuda.synchronize()
+    x = xs.prevSample.cpu().numpy().astype(np.float64)
+    for n, (k, p0, p1) in enumerate(targets):
+        for e in (0, 1, 255, 256, 40000, T - 1):
+            assert x[n, e] == pytest.approx(oracle.init_from_pdf(k, p0, p1, 123, 500 + e, n), rel=2e-4, abs=1e-5)
+    se = lambda m2, m4: np.sqrt((m4 - m2 * m2) / T)  # noqa: E731
+    r2 = (x ** 2).mean(axis=1)
+    assert r2[0] == pytest.approx(6.424247, abs=5 * se(r2[0], (x[0] ** 4).mean()) + 2e-3)
+    assert r2[1] == pytest.approx(30.413841, abs=5 * se(r2[1], (x[1] ** 4).mean()) + 1e-2)
+    assert r2[2] == pytest.approx(3.0, abs=5 * se(r2[2], (x[2] ** 4).mean()) + 2e-3)
+    xs.WarmupMetropolis(16, stepsize=2.2)
+    torch.cuda.synchronize()
+    y = xs.prevSample.cpu().numpy().astype(np.float64)
+    assert (y[0] ** 2).mean() == pytest.approx(6.424247, abs=5 * se(r2[0], (x[0] ** 4).mean()) + 2e-3)
+    # partition: a second engine holding events [700, 700+64) draws the same starts
+    part = _xs(dev, 4, 0, 64, targets, "recip_fast", seed=123, event_offset=700)
+    part.InitSampleFromPdf()
+    torch.cuda.synchronize()
+    assert np.array_equal(part.prevSample.cpu().numpy(), x[:, 200:264].astype(np.float32))
