@@ -49,3 +49,9 @@ clean:
 	rm -rf build $(LIB) mcmc_amd/host/stepsize mcmc_amd/host/xsection
 	$(MAKE) -C oracle clean
 .PHONY: all drivers oracle clean
+
+# VALU issue-rate microbenchmark (calibrates the cycle model of tools/isa_mix.py)
+ubench: tools/bin/ubench tools/bin/ubench2
+tools/bin/%: tools/%.hip
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<

@@ -168,6 +168,22 @@ def main():
                 traffic = pm["derived"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        # VALU issue occupancy: issue cycles of the hot loop's instruction mix (tools/isa_mix.py, costs from
+        # tools/ubench2.hip) over the SIMD cycles one wave-proposal actually took (1024 SIMDs, clock from the PMC run)
+        valu = None
+        try:
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r1_chain_kernel_isa_mix.json")))
+            ghz = pm["derived"]["clock_GHz"]
+            if args.rule == "cross" and args.math == "fast" and args.lags == 0:
+                cyc = 1024 * ghz * 1e9 * 64 * (kernel_ms * 1e-3) / launch_props
+                valu = {"measured_cycles_per_wave_proposal": cyc, "clock_GHz": ghz,
+                        "ideal_issue_cycles": mix["issue_cycles_per_wave_proposal_ideal"],
+                        "isolated_cost_issue_cycles": mix["issue_cycles_per_wave_proposal_isolated_costs"],
+                        "frac_of_ideal_issue": mix["issue_cycles_per_wave_proposal_ideal"] / cyc,
+                        "frac_of_isolated_cost_issue": mix["issue_cycles_per_wave_proposal_isolated_costs"] / cyc,
+                        "valu_insts_per_proposal": mix["valu_insts_per_proposal"]}
+        except (OSError, KeyError, ValueError, NameError):
+            pass
         achieved = FLOP_PER_PROPOSAL * launch_props / (kernel_ms * 1e-3) / 1e12
         out = {
             "metric": "MH proposals/sec", "value": value, "unit": "proposals/s", "n_gpus": world,
@@ -182,11 +198,12 @@ def main():
                          "frac": achieved / VALU_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "mcmc::chain_kernel", "kernel_ms": kernel_ms,
                          "flop_per_proposal": FLOP_PER_PROPOSAL, "proposals_per_launch": launch_props,
+                         "valu_issue": valu,
                          "note": "FP32 VALU-issue-bound (state in registers, no per-step HBM traffic). achieved = 24 "
                                  "algorithmic FP32 flop per proposal (SURVEY 8d) / kernel time; Philox integer work and "
                                  "quarter-rate transcendentals are not counted as flops, so frac understates VALU "
-                                 "occupancy (PMC: the kernel issues at the VALU limit of its instruction mix, DESIGN.md "
-                                 "4.1). traffic = HBM bytes per launch from the PMC passes under profiles/"},
+                                 "occupancy: valu_issue sets the issue cycles of the loop's instruction mix against the "
+                                 "cycles measured (the '% of VALU peak' of SURVEY 8d; DESIGN.md 4.1). traffic = HBM bytes per launch from the PMC passes under profiles/"},
             "estimates": {"mean_r": summ[0]["mean"], "var_r": summ[0]["variance"],
                           "acceptance": summ[0]["acceptance"]},
         }

@@ -79,6 +79,10 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 2 : 1) void chain_kernel(co
     const uint64_t t_end = p.step_offset + p.n_steps;
     const uint64_t nc = p.n_chains;
 
+    // the per-lane FP64 sums of y, y^2 run across the block's tiles and are reduced once at the end
+    double S1acc = 0.0, S2acc = 0.0;
+    uint64_t wacc_all = 0;
+
     for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const uint64_t chain = (uint64_t)tile * CHAIN_BLOCK + tid;
         const bool valid = chain < nc;
@@ -274,14 +278,10 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 2 : 1) void chain_kernel(co
                     ((Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch] = (Real)H[LAGPAD + k];
         }
 
-        // wave reductions -> per-wave LDS accumulators (only lane 0 of a wave touches its row)
-        const double r1 = wave_sum(valid ? S1 : 0.0);
-        const double r2 = wave_sum(valid ? S2 : 0.0);
-        if (lane == 0) {
-            sred[wave][0] += r1;
-            sred[wave][1] += r2;
-            sred[wave][2] += (double)wacc;
-        }
+        S1acc += valid ? S1 : 0.0;
+        S2acc += valid ? S2 : 0.0;
+        wacc_all += wacc;
+        // lag sums: wave reductions -> per-wave LDS accumulators (only lane 0 of a wave touches its row)
         if constexpr (NLAG > 0) {
 #pragma unroll
             for (int k = 0; k < NL; ++k) {
@@ -298,6 +298,15 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 2 : 1) void chain_kernel(co
         }
     }
 
+    {
+        const double r1 = wave_sum(S1acc);
+        const double r2 = wave_sum(S2acc);
+        if (lane == 0) {
+            sred[wave][0] = r1;
+            sred[wave][1] = r2;
+            sred[wave][2] = (double)wacc_all;
+        }
+    }
     __syncthreads();
     if (tid < len) {
         double tot = 0.0;

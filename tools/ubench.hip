@@ -20,10 +20,10 @@
 constexpr int ITERS = 4096;
 constexpr int ILP = 8;
 
-enum { OP_FMA, OP_MAD64, OP_MULHI, OP_MULLO, OP_XOR, OP_EXP, OP_RCP, OP_SIN, OP_LOG, OP_SQRT, OP_ADD64, OP_CVT, OP_N };
+enum { OP_FMA, OP_MAD64, OP_MULHI, OP_MULLO, OP_XOR, OP_EXP, OP_RCP, OP_SIN, OP_LOG, OP_SQRT, OP_ADD64, OP_CVT, OP_MAD64ACC, OP_N };
 static const char *names[OP_N] = {"v_fma_f32", "v_mad_u64_u32", "v_mul_hi_u32", "v_mul_lo_u32", "v_xor_b32",
                                   "v_exp_f32", "v_rcp_f32", "v_sin_f32", "v_log_f32", "v_sqrt_f32", "v_add_f64",
-                                  "v_cvt_f32_u32"};
+                                  "v_cvt_f32_u32", "v_mad_u64_u32 (acc)"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(float *out, float seed)
@@ -31,8 +31,10 @@ __global__ __launch_bounds__(256) void k(float *out, float seed)
     float f[ILP];
     unsigned u[ILP];
     double d[ILP];
+    unsigned long long a64[ILP];
 #pragma unroll
     for (int i = 0; i < ILP; ++i) {
+        a64[i] = threadIdx.x * 0x9E3779B97F4A7C15ull + i;
         f[i] = seed + threadIdx.x * 1e-3f + i;
         u[i] = threadIdx.x * 2654435761u + i;
         d[i] = f[i];
@@ -54,12 +56,14 @@ __global__ __launch_bounds__(256) void k(float *out, float seed)
             if constexpr (OP == OP_LOG) f[i] = __builtin_amdgcn_logf(f[i]);
             if constexpr (OP == OP_SQRT) f[i] = __builtin_amdgcn_sqrtf(f[i]);
             if constexpr (OP == OP_ADD64) d[i] = d[i] + 1.5;
+            // one v_mad_u64_u32 per op and nothing else: D = lo(D) * K + D
+            if constexpr (OP == OP_MAD64ACC) a64[i] = (unsigned long long)(unsigned)a64[i] * 0xD2511F53u + a64[i];
             if constexpr (OP == OP_CVT) f[i] = (float)(__builtin_bit_cast(unsigned, f[i]));
         }
     }
     float acc = 0;
 #pragma unroll
-    for (int i = 0; i < ILP; ++i) acc += f[i] + (float)u[i] + (float)d[i];
+    for (int i = 0; i < ILP; ++i) acc += f[i] + (float)u[i] + (float)d[i] + (float)a64[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
@@ -101,6 +105,7 @@ int main()
     run<OP_SQRT>(d_out, blocks);
     run<OP_ADD64>(d_out, blocks);
     run<OP_CVT>(d_out, blocks);
+    run<OP_MAD64ACC>(d_out, blocks);
     CHECK(hipFree(d_out));
     return 0;
 }
