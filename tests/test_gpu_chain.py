@@ -232,3 +232,40 @@ def test_tune_stepsize_reproduces_reference_optimum(dev):
     assert tau.min() < tau[0] and tau.min() < tau[-1]
     with pytest.raises(L.McmcError):
         api.TuneStepSize(api.make_target(L.TARGET_R2WS, 2.0, 0.54), 2.0, 1.0)
+
+
+def test_bench_size_properties(dev):
+    """BASELINE's full size (2^24 chains x 3 coordinates, the bench.py workload, CROSS rule / FAST math) through
+    size-independent properties: one launch == two half launches (states bit-identical, statistics additive);
+    slices of the id space re-run as small engines with chain_offset (first, an unaligned middle, the last 100
+    chains) reproduce the big run's states bit for bit; accepted-proposal count == steps * chains * acceptance;
+    <r^2> = 6.424247 within 3 standard errors."""
+    from mcmc_amd import lib as L
+    N, n = 1 << 24, 64
+    kw = dict(n_coords=3, target=R2WS_REF, step=2.48, precision=32, accept_rule=L.ACCEPT_CROSS, math_mode=L.MATH_FAST,
+              n_lags=0, center=2.3, seed=314159265)
+    a = _engine(dev, n_chains=N, **kw)
+    sa = a.run(n).clone()
+    b = _engine(dev, n_chains=N, **kw)
+    s1 = b.run(n // 2, window_start=True).clone()
+    s2 = b.run(n // 2, window_start=False).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a.state, b.state)
+    # the float partial sums are folded into FP64 at different steps in the two schedules: equal to rounding
+    np.testing.assert_allclose((s1 + s2).cpu().numpy(), sa.cpu().numpy(), rtol=1e-6)
+    assert (s1 + s2)[:, 2].cpu().tolist() == sa[:, 2].cpu().tolist()      # accepted proposals: exact
+    for off, cnt in ((0, 300), (5_000_123, 777), (N - 100, 100)):
+        h = _engine(dev, n_chains=cnt, chain_offset=off, **kw)
+        h.run(n)
+        torch.cuda.synchronize()
+        assert torch.equal(h.state, a.state[:, off:off + cnt]), off
+    st = sa.cpu().numpy()
+    assert np.all(st[:, 2] == np.round(st[:, 2])) and np.all(st[:, 2] <= N * n)
+    # equilibrium estimate after a warm-up (the first launch started every chain at x0 = 1)
+    a.run(400)
+    a.run(200, window_start=True)
+    torch.cuda.synchronize()
+    for sm in a.summary():
+        ex2 = sm["variance"] + sm["mean"] ** 2
+        assert abs(ex2 - 6.424247) < 3 * 5.3 * np.sqrt(2 * 6.0 / (N * 200.0)) + 2e-4, ex2
+        assert 0.40 < sm["acceptance"] < 0.42
