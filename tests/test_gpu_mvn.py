@@ -130,3 +130,43 @@ def test_mvn_argument_errors(dev):
     eng.args.dim = 12
     with pytest.raises(L.McmcError):
         eng.run(10)
+
+
+def test_mvn_stress_configuration_full_size(dev):
+    """BASELINE configs[4] at its per-GPU size: 2^21 chains x 64 dimensions, lag 1000 (8.4 GB ring), observable
+    written back every sweep.  Size-independent properties, all evaluated on the device: the lag-1000
+    autocorrelation from the ring accumulators == the one computed from the written-back series
+    (statistics.hpp:36-57, pooled over chains), mean/variance likewise, and the window split over two launches
+    gives the same state as one launch."""
+    N, dim, lag, n = 1 << 21, 64, 1000, 1100
+    eng, _, _ = _engine(dev, N, dim, 0.9, 0.8, lag, x0=0.0, seed=5)
+    ref, _, _ = _engine(dev, N, dim, 0.9, 0.8, lag, x0=0.0, seed=5)
+    eng.run(64, window=(0, 64 + lag))   # warm-up: its statistics are discarded (any window >= lag sweeps will do)
+    ref.run(64, window=(0, 64 + lag))
+    w = (eng.steps_done, eng.steps_done + n)
+    obs = torch.empty((n, N), dtype=torch.float32, device=dev)
+    tot = eng.run(700, window=w, samples_obs=obs[:700]).clone()
+    tot += eng.run(400, window=w, samples_obs=obs[700:])
+    ref.run(n, window=w)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.state, ref.state)
+    summ = eng.summary(tot.cpu().numpy(), n)
+    # statistics.hpp on the device, in FP64, chunked over chains
+    s1 = s2 = 0.0
+    for c in range(0, N, 1 << 18):
+        blk = obs[:, c:c + (1 << 18)].double()
+        s1 += blk.sum().item()
+        s2 += (blk * blk).sum().item()
+    cnt = float(n) * N
+    mu = s1 / cnt
+    var = (s2 - cnt * mu * mu) / (cnt - 1)
+    cov = 0.0
+    for c in range(0, N, 1 << 18):
+        blk = obs[:, c:c + (1 << 18)].double() - mu
+        cov += (blk[:-lag] * blk[lag:]).sum().item()
+    cov /= (float(n - lag) * N - 1)
+    assert summ["mean"] == pytest.approx(mu, abs=1e-6)
+    assert summ["variance"] == pytest.approx(var, rel=1e-5)
+    assert summ["rho_lag"] == pytest.approx(cov / var, abs=2e-5)
+    assert abs(summ["rho_lag"]) < 0.02          # lag 1000 >> tau_int of one coordinate of the AR(1) target
+    assert 0.2 < summ["acceptance"] < 0.9

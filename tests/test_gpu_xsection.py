@@ -69,7 +69,7 @@ def test_warmup_and_r2_injected(dev, oracle, mode, nN):
 
 
 @pytest.mark.parametrize("mode", ["recip_precise", "recip_fast"])
-@pytest.mark.parametrize("nA,nB", [(2, 2), (4, 4), (3, 5), (12, 12), (16, 20), (70, 70)])
+@pytest.mark.parametrize("nA,nB", [(2, 2), (4, 4), (3, 5), (12, 12), (16, 20), (70, 70), (208, 208), (197, 63)])
 @pytest.mark.parametrize("b", [0.0, 1.5])
 def test_sab_injected(dev, oracle, mode, nA, nB, b):
     """a12: per-thread Kahan mean of prod (1 - Gamma), plus black-disk hit counters."""
@@ -319,3 +319,35 @@ def test_init_from_pdf_matches_oracle_and_is_stationary(dev, oracle):
     part.InitSampleFromPdf()
     torch.cuda.synchronize()
     assert np.array_equal(part.prevSample.cpu().numpy(), x[:, 200:264].astype(np.float32))
+
+
+def test_sab_heavy_ion_full_size_partition(dev):
+    """C4 at the size of tools/run_c4.sh (Pb-208 + Pb-208, 2^14 events per launch): slices of the event id space
+    re-run as small engines with event_offset reproduce the big launch's per-event S_AB, hit counters and chain
+    states bit for bit (what makes the multi-GPU event partition exact), and S_AB rises with b."""
+    nA = nB = 208
+    PB = (O.R2WS, 6.62, 0.546)
+    T, samples, dmax2 = 1 << 14, 4, 6.76 / np.pi
+    big = _xs(dev, nA, nB, T, [PB] * 416, "nodiv_fast", seed=99, sigmaNN=6.76)
+    big.InitSampleFromPdf()
+    big.WarmupMetropolis(32, stepsize=3.9)
+    start = big.prevSample.clone()
+    res, mean, hits = big.MCIntegrate_S_AB(samples, 13.0, stepsize=3.9, dmax2=dmax2)
+    torch.cuda.synchronize()
+    res_big, hits_big, state_big = res.clone(), hits.clone(), big.prevSample.clone()
+    tot = torch.zeros(3, dtype=torch.float64, device=dev)
+    for off, cnt in ((0, 64), (7001, 100), (T - 50, 50)):
+        part = _xs(dev, nA, nB, cnt, [PB] * 416, "nodiv_fast", seed=99, sigmaNN=6.76, event_offset=off)
+        part.prevSample.copy_(start[:, off:off + cnt])
+        part.args.step_offset = 32
+        r, _, h = part.MCIntegrate_S_AB(samples, 13.0, stepsize=3.9, dmax2=dmax2)
+        torch.cuda.synchronize()
+        assert torch.equal(r, res_big[off:off + cnt]) and torch.equal(part.prevSample, state_big[:, off:off + cnt])
+        tot += h[:3]
+    assert torch.all(tot <= hits_big[:3]) and hits_big[3].item() == T * samples
+    s = []
+    for b in (11.0, 13.0, 15.0, 17.0):
+        _, m, _ = big.MCIntegrate_S_AB(samples, b, stepsize=3.9)
+        torch.cuda.synchronize()
+        s.append(m.item())
+    assert s[0] < s[1] < s[2] < s[3] and s[0] < 0.05 and s[3] > 0.9
