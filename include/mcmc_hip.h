@@ -200,7 +200,8 @@ typedef struct {
     const mcmc_target *targets; /* dev [nNucleonsA+nNucleonsB] per-nucleon density (main.cu:47-51)    */
     float *prevSample;          /* dev [nNucleons][totalThreads]; main.cu:126                         */
     float stepsize;             /* main.cu:149,197,335 (2.2f)                                         */
-    int32_t accept_rule;        /* MCMC_ACCEPT_RECIP or MCMC_ACCEPT_NODIV                              */
+    int32_t accept_rule;        /* MCMC_ACCEPT_RECIP, _NODIV or _CROSS (CROSS: warm-up and R2 kernels; the
+                                   S_AB kernel then applies the same decision p' >= U p as NODIV)      */
     int32_t math_mode;
     int32_t uniform_kind;       /* -1: kinds differ per nucleon (read from `targets` on the device);
                                    otherwise every nucleon has this mcmc_target_kind, which selects a

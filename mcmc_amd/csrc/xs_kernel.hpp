@@ -128,8 +128,12 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
     const uint32_t nN = p.nA + p.nB;
     const uint64_t idx = (uint64_t)n * p.T + e;
     float x = p.prevSample[idx];
-    float aux = mh_aux_init<KIND, RULE, MATH>(tg, x);
+    float aux, aux2;
+    mh_aux_init<KIND, RULE, MATH>(tg, x, aux, aux2);
     float sum = 0.0f, err = 0.0f;
+    // Philox draws in FAST math: the proposal width is folded into the Box-Muller radius (as chain_kernel)
+    constexpr bool PRESCALED = !INJ && MATH == MCMC_MATH_FAST;
+    const float scale2 = -1.3862943611198906f * p.stepsize * p.stepsize;
     const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
     const uint64_t gid = p.event_offset + e;
 
@@ -139,7 +143,8 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
             z = d[0];
             u = d[1];
         }
-        mh_step<KIND, RULE, MATH>(tg, x, aux, p.stepsize, z, u);
+        // Metropolis.cuh:43: mul + add, two roundings (PRESCALED: z already is stepsize * normal)
+        mh_step_dz<KIND, RULE, MATH>(tg, x, aux, aux2, PRESCALED ? z : p.stepsize * z, u);
         if constexpr (R2) { // IntegrateR2.cuh:38-46
             float y = x * x;
             y -= err;
@@ -158,7 +163,7 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
             float z0 = 0, z1 = 0, u0 = 0, u1 = 0;
             if constexpr (!INJ) {
                 const u32x4 w = pair_words<J>(p.seed, gid, n, g, sp);
-                pair_draws_f32<MATH, false>(w, 0.0f, z0, z1, u0, u1);
+                pair_draws_f32<MATH, PRESCALED>(w, scale2, z0, z1, u0, u1);
             }
             const uint64_t t0 = (g << 3) + 2 * J;
             if (FULL || (t0 >= ta && t0 < tb)) one(t0, z0, u0);

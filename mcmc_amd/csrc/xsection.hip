@@ -24,8 +24,8 @@ int check_xs(const mcmc_xs_args *a)
     if (a->totalThreads == 0) return set_error(MCMC_EINVAL, "totalThreads must be > 0");
     if (a->totalThreads > (1ull << 40)) return set_error(MCMC_EINVAL, "totalThreads must be <= 2^40");
     if (!a->targets || !a->prevSample) return set_error(MCMC_EINVAL, "targets and prevSample must be device pointers");
-    if (a->accept_rule != MCMC_ACCEPT_RECIP && a->accept_rule != MCMC_ACCEPT_NODIV)
-        return set_error(MCMC_EINVAL, "xsection kernels implement MCMC_ACCEPT_RECIP and MCMC_ACCEPT_NODIV");
+    if (a->accept_rule != MCMC_ACCEPT_RECIP && a->accept_rule != MCMC_ACCEPT_NODIV && a->accept_rule != MCMC_ACCEPT_CROSS)
+        return set_error(MCMC_EINVAL, "xsection kernels implement MCMC_ACCEPT_RECIP, MCMC_ACCEPT_NODIV and MCMC_ACCEPT_CROSS");
     if (a->math_mode == MCMC_MATH_PRECISE && a->accept_rule != MCMC_ACCEPT_RECIP)
         return set_error(MCMC_EINVAL, "precise math implements MCMC_ACCEPT_RECIP only");
     if (a->math_mode != MCMC_MATH_PRECISE && a->math_mode != MCMC_MATH_FAST) return set_error(MCMC_EINVAL, "bad math_mode");
@@ -67,6 +67,9 @@ int launch_chain_xs(const mcmc_xs_args *a, const XsParams &p, hipStream_t s)
     } else if (a->accept_rule == MCMC_ACCEPT_RECIP) {
         if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, true, R2>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, false, R2>), grid, block, 0, s, p);
+    } else if (a->accept_rule == MCMC_ACCEPT_CROSS) {
+        if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, true, R2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, false, R2>), grid, block, 0, s, p);
     } else {
         if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, true, R2>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, false, R2>), grid, block, 0, s, p);

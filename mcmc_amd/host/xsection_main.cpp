@@ -69,7 +69,7 @@ int main(int argc, char **argv)
             }
             std::puts("usage: xsection [name=value ...]   names: nNeutronA nProtonA nNeutronB nProtonB isotopeA isotopeB pdf pdfA\n"
                       "       pdfB totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix b0 db ndbs seed stepsize\n"
-                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk inelOnly randomStart math device");
+                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk inelOnly randomStart rule math device");
             return a == "--help" || a == "-h" ? 0 : 2;
         }
         const std::string k = a.substr(0, eq), v = a.substr(eq + 1);
@@ -108,6 +108,8 @@ int main(int argc, char **argv)
         else if (k == "sigmaNN") cfg.sigmaNN = fv;
         else if (k == "beta") cfg.beta = fv;
         else if (k == "device") cfg.device = iv;
+        else if (k == "rule") // acceptance test: the reference's p'(1/p) >= U, or the reciprocal-free forms of p' >= U p
+            cfg.accept_rule = v == "cross" ? MCMC_ACCEPT_CROSS : v == "nodiv" ? MCMC_ACCEPT_NODIV : MCMC_ACCEPT_RECIP;
         else if (k == "math") cfg.math_mode = v == "precise" ? MCMC_MATH_PRECISE : MCMC_MATH_FAST;
         else if (k == "outDir") outDir = v;
         else if (k == "outFile") outFile = v;

@@ -18,7 +18,7 @@ WS20 = (O.R2WS, 2.0, 0.54)  # main.cu:14-19
 def _modes():
     from mcmc_amd import lib as L
     return {"recip_precise": (L.ACCEPT_RECIP, L.MATH_PRECISE), "recip_fast": (L.ACCEPT_RECIP, L.MATH_FAST),
-            "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST)}
+            "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "cross_fast": (L.ACCEPT_CROSS, L.MATH_FAST)}
 
 
 def _xs(dev, nA, nB, T, targets, mode="recip_precise", **kw):
@@ -35,7 +35,7 @@ def _draws(rng, T, L):
     return d
 
 
-@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast"])
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast", "cross_fast"])
 @pytest.mark.parametrize("nN", [1, 3, 8])
 def test_warmup_and_r2_injected(dev, oracle, mode, nN):
     """a8 + a10: final state and per-thread Kahan means of r^2 (IntegrateR2.cuh:33-52)."""

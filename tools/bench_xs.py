@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--rule", default="recip")
     ap.add_argument("--which", default="c3,c4,he")
     args = ap.parse_args()
-    rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV}[args.rule]
+    rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "cross": L.ACCEPT_CROSS}[args.rule]
     dev = torch.device("cuda:0")
     which = args.which.split(",")
     if "c3" in which:

@@ -16,5 +16,5 @@ grep -v "^Nucleon" $OUT/stdout.txt
 grep "^Nucleon" $OUT/stdout.txt | awk '{s+=$6; n++} END{print "mean nucleon RMS", s/n, "fm over", n, "nucleons (quadrature 5.514875)"}'
 ./mcmc_amd/host/xsection isotopeA=PB-208 isotopeB=PB-208 pdf=r2ws:6.62:0.546 sigmaNN=6.76 beta=0.2 \
     totalBlocks=128 threadsPerBlock=128 samplesPerThread=64 totalRuns=8 samplesForMix=8192 \
-    b0=0.05 db=0.1 ndbs=200 inelOnly=1 integrateRMS=0 outDir=$OUT outFile=pbpb > $OUT/stdout_inel.txt
+    b0=0.05 db=0.1 ndbs=200 inelOnly=1 rule=cross randomStart=1 integrateRMS=0 outDir=$OUT outFile=pbpb > $OUT/stdout_inel.txt
 cat $OUT/stdout_inel.txt
