@@ -269,3 +269,46 @@ def test_bench_size_properties(dev):
         ex2 = sm["variance"] + sm["mean"] ** 2
         assert abs(ex2 - 6.424247) < 3 * 5.3 * np.sqrt(2 * 6.0 / (N * 200.0)) + 2e-4, ex2
         assert 0.40 < sm["acceptance"] < 0.42
+
+
+def test_randomised_configurations_against_oracle_stream(dev, oracle):
+    """Differential test over 24 seeded random configurations (density, rule, width, 64-bit seed, chain offsets up
+    to 2^39, step offsets up to 2^40 that start and end inside a group of 8 packed steps, 1..40 steps, ragged chain
+    counts, a second launch continuing the first): the Philox-mode trajectory of sampled chains == the oracle's
+    step logic driven by the ORACLE's own restatement of the packed draw stream (orc_mh_draws_f32)."""
+    from mcmc_amd import lib as L
+    rng = np.random.default_rng(20260101)
+    kinds = [R2WS_REF, R2GAUSS_1, (O.WS, 2.0, 0.54), (O.GAUSS, 1.5, 0.0)]
+    rules = [(L.ACCEPT_RECIP, L.MATH_PRECISE, 1e-6), (L.ACCEPT_RECIP, L.MATH_FAST, 2e-4), (L.ACCEPT_NODIV, L.MATH_FAST, 2e-4),
+             (L.ACCEPT_CROSS, L.MATH_FAST, 2e-4), (L.ACCEPT_LOG, L.MATH_FAST, 2e-4)]
+    strict = total = 0
+    for case in range(24):
+        tgt = kinds[case % 4]
+        rule, math, tol = rules[case % 5]
+        n_chains = int(rng.choice([1, 63, 65, 257, 300]))
+        n_coords = int(rng.integers(1, 4))
+        seed = int(rng.integers(0, 1 << 63))
+        off = int(rng.integers(0, (1 << 39) - n_chains))
+        t0 = int(rng.integers(0, 1 << 40))
+        n1, n2 = int(rng.integers(1, 41)), int(rng.integers(1, 20))
+        step = float(rng.uniform(0.5, 4.0))
+        eng = _engine(dev, n_chains=n_chains, n_coords=n_coords, target=tgt, step=step, precision=32, accept_rule=rule,
+                      math_mode=math, seed=seed, chain_offset=off)
+        eng.steps_done = t0
+        n = n1 + n2
+        samples = torch.empty((n, n_coords, n_chains), dtype=torch.float32, device=dev)
+        bits = torch.zeros((n, n_coords, n_chains), dtype=torch.uint8, device=dev)
+        eng.run(n1, samples=samples[:n1], accept_bits=bits[:n1])
+        eng.run(n2, samples=samples[n1:], accept_bits=bits[n1:])
+        torch.cuda.synchronize()
+        s, b = samples.cpu().numpy(), bits.cpu().numpy()
+        for c in {0, n_chains - 1, n_chains // 2}:
+            for k in range(n_coords):
+                d = np.array([oracle.mh_draws_f32(seed, off + c, k, t0 + t) for t in range(n)], dtype=np.float32)
+                _, rb, trace, margin = oracle.warmup_thread_trace([tgt], [1.0], step, n, d.reshape(n, 1, 2))
+                total += 1
+                if margin > 1e-4:
+                    strict += 1
+                    assert np.array_equal(b[:, k, c], rb[:, 0]), (case, c, k)
+                    np.testing.assert_allclose(s[:, k, c], trace[:, 0], rtol=tol, atol=tol)
+    assert strict >= 0.6 * total
