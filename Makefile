@@ -51,7 +51,7 @@ clean:
 .PHONY: all drivers oracle clean
 
 # VALU issue-rate microbenchmark (calibrates the cycle model of tools/isa_mix.py)
-ubench: tools/bin/ubench tools/bin/ubench2
+ubench: tools/bin/ubench tools/bin/ubench2 tools/bin/ubench3
 tools/bin/%: tools/%.hip
 	@mkdir -p tools/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
