@@ -54,7 +54,7 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 // Real = double: metropolis.hpp:35-47 arithmetic (rule SHORTCIRCUIT)
 // STORE: sample / accept-flag write-back requested (keeps the address arithmetic out of the hot loop otherwise)
 template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, bool STORE>
-__global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 2 : 1) void chain_kernel(const ChainParams p)
+__global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(const ChainParams p)
 {
     constexpr int NL = NLAG > 0 ? NLAG : 1;
     __shared__ double sred[CHAIN_WAVES][3 + 3 * NL];
