@@ -78,6 +78,22 @@ def test_argument_errors_need_no_device():
     assert lib.mcmc_chain_workspace_bytes(C.byref(a)) == 1 * 1 * L.stats_len(4) * 8
     out = (C.c_double * 6)()
     assert lib.mcmc_cross_sections(None, None, None, 0, out) == -1
+    # maximum size: the Philox counter carries 40 bits of chain id
+    big = L.ChainArgs()
+    big.n_chains, big.n_coords, big.n_steps, big.state, big.stats = (1 << 39) + 1, 1, 8, 1, 1
+    assert lib.mcmc_chain_run(C.byref(big), None) == -1
+    # entry points added after the first ABI: null / empty arguments are refused before any device call
+    assert lib.mcmc_launch_integrate_inel(None, 1, 0.0, None, 1.0, None) == -1
+    assert lib.mcmc_launch_init_sample_from_pdf(None, None) == -1
+    assert lib.mcmc_run_inel_scan(None, None, None, None, 1.0) == -1
+    assert lib.mcmc_init_from_pdf(None) == -1
+    best = C.c_double()
+    tgt = L.Target(L.TARGET_R2WS, 2.0, 0.54)
+    assert lib.mcmc_tune_stepsize(C.byref(tgt), 2.0, 1.0, 5, 64, 10, 100, 1, 1.0, None, None, None, C.byref(best)) == -1
+    assert lib.mcmc_tune_stepsize(C.byref(tgt), 1.0, 2.0, 5, 64, 10, 20, 1, 1.0, None, None, None, C.byref(best)) == -1
+    assert b"MCMC_MAX_LAGS" in lib.mcmc_last_error()
+    m = L.MvnArgs()
+    assert lib.mcmc_mvn_run(C.byref(m), None) == -1
 
 
 def test_product_does_not_import_the_oracle():
