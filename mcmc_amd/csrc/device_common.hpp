@@ -30,9 +30,11 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
         u32x4 n;
-        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        // three-input xor in one instruction: gfx950's v_bitop3_b32 with truth table 0x96 (a ^ b ^ c) issues
+        // at the rate of a plain v_xor_b32 (tools/ubench3.hip); hipcc does not form it from two xors by itself
+        n.x = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k0, 0x96);
         n.y = (uint32_t)p1;
-        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.z = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k1, 0x96);
         n.w = (uint32_t)p0;
         c = n;
         k0 += 0x9E3779B9u;

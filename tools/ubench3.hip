@@ -86,6 +86,10 @@ KERNEL(k_perm_sgpr, TRI8("v_perm_b32", "s21"))
 KERNEL(k_bfi_vgpr, TRI8("v_bfi_b32", "v30"))
 KERNEL(k_xad_vgpr, TRI8("v_xad_u32", "v30"))
 KERNEL(k_add3_vgpr, TRI8("v_add3_u32", "v30"))
+#define TRI8B(C) "v_bitop3_b32 v10, v21, v10, " C " bitop3:0x96\n v_bitop3_b32 v11, v22, v11, " C " bitop3:0x96\n v_bitop3_b32 v12, v23, v12, " C " bitop3:0x96\n v_bitop3_b32 v13, v24, v13, " C " bitop3:0x96\n " \
+                "v_bitop3_b32 v14, v25, v14, " C " bitop3:0x96\n v_bitop3_b32 v15, v26, v15, " C " bitop3:0x96\n v_bitop3_b32 v16, v27, v16, " C " bitop3:0x96\n v_bitop3_b32 v17, v28, v17, " C " bitop3:0x96\n"
+KERNEL(k_bitop3_vgpr, TRI8B("v30"))
+KERNEL(k_bitop3_sgpr, TRI8B("s21"))
 KERNEL(k_cmp_vcc, "v_cmp_ge_f32 vcc, v10, v21\n v_cmp_ge_f32 vcc, v11, v22\n v_cmp_ge_f32 vcc, v12, v23\n v_cmp_ge_f32 vcc, v13, v24\n"
                   "v_cmp_ge_f32 vcc, v14, v25\n v_cmp_ge_f32 vcc, v15, v26\n v_cmp_ge_f32 vcc, v16, v27\n v_cmp_ge_f32 vcc, v17, v28\n")
 KERNEL(k_cnd_vcc, "v_cndmask_b32 v10, v21, v10, vcc\n v_cndmask_b32 v11, v22, v11, vcc\n v_cndmask_b32 v12, v23, v12, vcc\n v_cndmask_b32 v13, v24, v13, vcc\n"
@@ -133,6 +137,7 @@ int main()
         {"v_alignbit_b32 vgpr, vgpr, 9", k_alignbit_const}, {"v_perm_b32 vgpr selector", k_perm_vgpr},
         {"v_perm_b32 sgpr selector", k_perm_sgpr}, {"v_bfi_b32 vgpr", k_bfi_vgpr}, {"v_xad_u32 vgpr", k_xad_vgpr},
         {"v_add3_u32 vgpr", k_add3_vgpr},
+        {"v_bitop3_b32 (xor3) vgpr", k_bitop3_vgpr}, {"v_bitop3_b32 (xor3) sgpr key", k_bitop3_sgpr},
         {"v_cmp_ge_f32 -> vcc", k_cmp_vcc}, {"v_cndmask_b32 (vcc)", k_cnd_vcc}, {"v_cmp + 3 v_cndmask (x2)", k_cmp_cnd3},
         {"v_exp_f32 (again)", k_exp},
     };
