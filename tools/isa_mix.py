@@ -3,8 +3,9 @@
 proposals), from hipcc -S of mcmc_amd/csrc/chain_kind.hip with the Makefile's flags.  Gives the VALU issue
 cycles per wave-proposal that bench.py sets against the measured rate.  Issue costs per wave64 instruction
 (SIMD cycles), from tools/ubench2.hip on MI355X (profiles/r1_valu_issue_costs.txt, anchored on v_exp_f32 = 8):
-    ideal model   : 2 for full-rate ops, 4 for the class that measures 4.1-4.3 (v_mad_u64_u32, v_alignbit_b32,
-                    v_perm_b32, v_max_f32, v_cmp_*), 8 for transcendentals
+    ideal model   : 2 for full-rate ops (v_bitop3_b32 included), 4 for the class that measures 4.0-4.3 with
+                    VGPR operands only (v_mad_u64_u32, v_alignbit_b32, v_perm_b32, v_max_f32, v_cmp_*, ...),
+                    8 for transcendentals
     isolated costs: what each instruction showed alone (full-rate ops 2.3-2.9 instead of 2)
 The kernel cannot beat the ideal model; the second is what the same instructions achieve in a loop of their own.
 Runs in the build container (no GPU needed)."""
@@ -19,8 +20,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "_ZN4mcmc12chain_kernelIfLi1ELi4ELi1ELi0ELb0ELb0EEEvNS_11ChainParamsE"  # float, R2WS, CROSS, FAST, no lags
 QUARTER = re.compile(r"^v_(exp_f32|log_f32|rcp_f32|rsq_f32|sqrt_f32|sin_f32|cos_f32)")
-HALF = re.compile(r"^v_(mad_u64_u32|alignbit_b32|perm_b32|max_f32|min_f32|cmp_)")
-ISOLATED = {"v_xor_b32_e32": 2.93, "v_add_f32_e32": 2.57, "v_sub_f32_e32": 2.43, "v_mul_f32_e32": 2.31, "v_fma_f32": 2.89,
+HALF = re.compile(r"^v_(mad_u64_u32|mul_hi_u32|mul_lo_u32|alignbit_b32|perm_b32|bfi_b32|xad_u32|add3_u32|max_f32|min_f32|cmp_)")
+ISOLATED = {"v_xor_b32_e32": 2.93, "v_bitop3_b32": 2.24, "v_add_f32_e32": 2.57, "v_sub_f32_e32": 2.43, "v_mul_f32_e32": 2.31, "v_fma_f32": 2.89,
             "v_fmac_f32_e32": 2.80, "v_alignbit_b32": 4.14, "v_perm_b32": 4.14, "v_mad_u64_u32": 4.29, "v_max_f32_e32": 4.08,
             "v_cmp_ge_f32_e32": 4.29}  # cycles; anything else: its class in the ideal model
 
@@ -64,7 +65,7 @@ def main():
            "valu_insts_per_proposal": n_valu / proposals, "quarter_rate_per_proposal": n_q / proposals,
            "issue_cycles_per_wave_proposal_ideal": ideal / proposals,
            "issue_cycles_per_wave_proposal_isolated_costs": isolated / proposals,
-           "philox_insts": valu.get("v_mad_u64_u32", 0) + valu.get("v_xor_b32_e32", 0),
+           "philox_insts": valu.get("v_mad_u64_u32", 0) + valu.get("v_xor_b32_e32", 0) + valu.get("v_bitop3_b32", 0),
            "histogram": dict(sorted(hist.items(), key=lambda kv: -kv[1]))}
     json.dump(res, sys.stdout, indent=1)
     print()
