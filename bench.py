@@ -163,7 +163,7 @@ def main():
         # FETCH_SIZE / WRITE_SIZE in their own runs, FETCH doubled per MI355X_MICROARCH.md), else null
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_chain_kernel_v5.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_chain_kernel_v6.json")))
             if args.chains == 1 << 24 and args.coords == 3 and args.lags == 0:
                 traffic = pm["derived"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
