@@ -43,3 +43,57 @@ def max_over_ranks(seconds, device=None, group=None):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+# --- the Glauber impact-parameter scan, events sharded over ranks -------------------
+# Rank r owns the events [offset, offset + count) of the global id space (XsEngine(event_offset=offset)),
+# runs EVERY impact parameter on them, and writes four numbers per (b, run) into one device tensor;
+# ONE all-reduce(SUM) of that tensor is the whole exchange.  The reference's estimator (main.cu:359,
+# 384-389: mean over threads per run, then Average / Variance over runs) is evaluated on the totals.
+SCAN_COLS = 4  # sum over events of the per-event S_AB mean | events | samples with >= 1 collision | samples
+
+
+def glauber_scan(engine, b_values, samples, runs, dmax2=None, inel_only=False):
+    """All launches of the scan queued on the current stream; returns the [len(b)][runs][SCAN_COLS] float64
+    device tensor of THIS rank's contributions (no host synchronisation)."""
+    stats = torch.zeros((len(b_values), int(runs), SCAN_COLS), dtype=torch.float64, device=engine.device)
+    for i, b in enumerate(b_values):
+        for r in range(int(runs)):
+            row = stats[i, r]
+            if inel_only:
+                hits = engine.MCIntegrate_Inel(samples, float(b), dmax2)
+                row[2:4] = hits[0:2]
+            else:
+                _, mean, hits = engine.MCIntegrate_S_AB(samples, float(b), dmax2=dmax2)
+                row[0] = mean[0] * engine.T
+                if hits is not None:
+                    row[2] = hits[1]
+                    row[3] = hits[3]
+            row[1] = engine.T
+    return stats
+
+
+def finalize_scan(stats_total, b_values):
+    """Host side, on the all-reduced tensor: per b the reference's run estimator of S_AB (FP32 Kahan Average /
+    Variance through the C ABI, main.cu:384-386), the black-disk inelastic probability, and the cross sections
+    (XSectionAnalysis.py:3-28 via mcmc_cross_sections; sigma_inel by the same trapezoid rule)."""
+    import numpy as np
+    from . import api
+    st = np.asarray(stats_total, dtype=np.float64)
+    b = np.asarray(b_values, dtype=np.float64)
+    nb, runs, _ = st.shape
+    out = {"b": b, "S_AB": np.zeros(nb), "S_AB_stderr": np.zeros(nb), "p_inel": np.zeros(nb)}
+    for i in range(nb):
+        run_means = (st[i, :, 0] / np.maximum(st[i, :, 1], 1.0)).astype(np.float32)   # main.cu:359
+        avg = api.Average(run_means)
+        out["S_AB"][i] = avg
+        out["S_AB_stderr"][i] = np.sqrt(api.Variance(run_means, avg) / runs) if runs > 1 else 0.0
+        tot = st[i, :, 3].sum()
+        out["p_inel"][i] = st[i, :, 2].sum() / tot if tot > 0 else 0.0
+    if nb >= 2:
+        if st[:, :, 0].any():
+            out["sigma"] = api.CrossSections(b, out["S_AB"], out["S_AB_stderr"])
+        if st[:, :, 3].any():
+            w = b * out["p_inel"]
+            out["sigma_inel_mb"] = 10.0 * 2.0 * np.pi * float(np.sum(0.5 * (w[1:] + w[:-1]) * np.diff(b)))
+    return out

@@ -83,3 +83,57 @@ def test_two_rank_gloo_allreduce_equals_single_process():
     ref = api.finalize_stats(whole[0], 0, N_CHAINS, SWEEPS, 0.0)
     assert out["mean"] == pytest.approx(ref["mean"], rel=1e-13)
     assert out["acceptance"] == ref["acceptance"]
+
+
+def _scan_rank_stats(rank, nb=7, runs=3):
+    """Synthetic per-rank contributions of the Glauber scan: [b][run][sum S_AB, events, inelastic samples, samples]."""
+    rng = np.random.default_rng(100 + rank)
+    events = 500 + rank
+    st = np.zeros((nb, runs, 4))
+    s_ab = np.linspace(0.0, 1.0, nb)[:, None] + 0.01 * rng.standard_normal((nb, runs))
+    st[:, :, 0] = s_ab * events
+    st[:, :, 1] = events
+    st[:, :, 3] = events * 16
+    st[:, :, 2] = np.floor(st[:, :, 3] * np.linspace(1.0, 0.0, nb)[:, None])
+    return st
+
+
+def _scan_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mcmc_amd import dist as D
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        st = torch.from_numpy(_scan_rank_stats(rank))
+        D.allreduce_stats(st)
+        res = D.finalize_scan(st.numpy(), np.arange(7) * 2.0)
+        q.put((rank, res["S_AB"].copy(), res["S_AB_stderr"].copy(), res["p_inel"].copy(), res["sigma_inel_mb"],
+               res["sigma"]["rxn"][0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_glauber_scan_reduction():
+    """The C4 sharding: per-rank [b][run][4] tensors, ONE all-reduce, the reference's run estimator (main.cu:359,
+    384-386) and the cross sections evaluated on the totals == the same evaluation of the directly summed tensors."""
+    from mcmc_amd import dist as D
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = D.finalize_scan(_scan_rank_stats(0) + _scan_rank_stats(1), np.arange(7) * 2.0)
+    for _, s, e, pin, sig_inel, sig_rxn in res:
+        np.testing.assert_allclose(s, whole["S_AB"], rtol=1e-7)
+        np.testing.assert_allclose(e, whole["S_AB_stderr"], rtol=1e-5)
+        np.testing.assert_allclose(pin, whole["p_inel"], rtol=1e-14)
+        assert sig_inel == pytest.approx(whole["sigma_inel_mb"], rel=1e-13)
+        assert sig_rxn == pytest.approx(whole["sigma"]["rxn"][0], rel=1e-6)
+    assert whole["S_AB"][0] < 0.05 and whole["S_AB"][-1] > 0.95 and np.all(whole["S_AB_stderr"] > 0)
+    assert whole["p_inel"][0] == 1.0 and whole["p_inel"][-1] == 0.0

@@ -351,3 +351,33 @@ def test_sab_heavy_ion_full_size_partition(dev):
         torch.cuda.synchronize()
         s.append(m.item())
     assert s[0] < s[1] < s[2] < s[3] and s[0] < 0.05 and s[3] > 0.9
+
+
+def test_glauber_scan_event_sharding_is_exact(dev):
+    """mcmc_amd.dist.glauber_scan: two engines holding the two halves of the event id space (what two ranks run)
+    give, summed, the statistics tensor of one engine over all events -- inelastic counts exactly, S_AB sums to
+    FP64 rounding -- for the full and the inelastic-only scan; finalize_scan then yields S_AB(b) rising with b."""
+    from mcmc_amd import dist as D
+    nA = nB = 12
+    tg = [WS20] * (nA + nB)
+    T, samples, runs, dmax2 = 600, 8, 2, 4.3 / np.pi
+    b = np.array([0.0, 2.0, 4.0, 8.0])
+
+    def scan(off, cnt, inel_only):
+        e = _xs(dev, nA, nB, cnt, tg, "nodiv_fast", seed=11, event_offset=off)
+        e.InitSampleFromPdf()
+        e.WarmupMetropolis(64, stepsize=2.4)
+        return D.glauber_scan(e, b, samples, runs, dmax2=dmax2, inel_only=inel_only)
+
+    for inel_only in (False, True):
+        whole = scan(0, T, inel_only)
+        parts = scan(0, 250, inel_only) + scan(250, 350, inel_only)
+        torch.cuda.synchronize()
+        w, p = whole.cpu().numpy(), parts.cpu().numpy()
+        assert np.array_equal(w[:, :, 1:], p[:, :, 1:])
+        np.testing.assert_allclose(p[:, :, 0], w[:, :, 0], rtol=1e-12)
+        res = D.finalize_scan(w, b)
+        assert res["p_inel"][0] > 0.9 and res["p_inel"][-1] < 0.05 and "sigma_inel_mb" in res
+        if not inel_only:
+            assert res["S_AB"][0] < res["S_AB"][1] < res["S_AB"][2] < res["S_AB"][3] and res["S_AB"][3] > 0.98
+            assert res["sigma"]["rxn"][0] > 0
