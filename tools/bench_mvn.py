@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--chains", type=int, default=1 << 21)
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--lag", type=int, default=1000)
-    ap.add_argument("--sweeps", type=int, default=16)
+    ap.add_argument("--sweeps", type=int, default=64)
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--step", type=float, default=0.8)
     args = ap.parse_args()
