@@ -86,7 +86,10 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
     for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const uint64_t chain = (uint64_t)tile * CHAIN_BLOCK + tid;
         const bool valid = chain < nc;
-        const uint64_t ch = valid ? chain : 0; // clamp so that every lane runs the same code on legal addresses
+        // Lanes past the end (last tile only) replay the LAST chain, which lives in this same tile: same start,
+        // same draws, same trajectory -- so their per-step stores hit that chain's slots with that chain's
+        // values and need no exec masking; only the statistics leave them out.
+        const uint64_t ch = valid ? chain : nc - 1;
         const uint64_t gid = p.chain_offset + ch;
         Real *state = (Real *)p.state + (uint64_t)coord * nc + ch;
 
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
             }
             if constexpr (STORE) {
                 // written once, never re-read by this kernel: streaming (nt) stores keep them out of L2's way
-                if (p.samples != nullptr && valid) __builtin_nontemporal_store(x, (Real *)p.samples + slot);
-                if (p.accept_bits != nullptr && valid) __builtin_nontemporal_store((uint8_t)(take ? 1 : 0), p.accept_bits + slot);
+                if (p.samples != nullptr) __builtin_nontemporal_store(x, (Real *)p.samples + slot);
+                if (p.accept_bits != nullptr) __builtin_nontemporal_store((uint8_t)(take ? 1 : 0), p.accept_bits + slot);
             }
         };
 
@@ -268,7 +271,6 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
             }
         }
 
-        // clamped (invalid) lanes replayed chain 0 on a possibly stale read: they never store
         if (valid) *state = x;
 
         if (NLAG > 0 && p.ring != nullptr && valid) {
