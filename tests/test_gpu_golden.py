@@ -86,3 +86,43 @@ def test_sigma_against_reference_python_vectors(dev):
     g = np.load(os.path.join(GOLD, "sigma_f1.npz"))
     cs = api.CrossSections(g["b"], g["S_AB"], g["S_AB_stderr"])
     np.testing.assert_allclose([cs["tot"][0], cs["el"][0], cs["rxn"][0]], g["ref_sigma"][[0, 2, 4]], rtol=1e-12)
+
+
+def test_xsection_against_the_reference_recorded_run(dev):
+    """The one xsection OUTPUT the reference holds (XSectionAnalysis.ipynb cells 1 and 5: C-12 + C-12, r^2 WS(c, 0.54),
+    200 impact parameters): the whole device path -- warm-up, S_AB scan, run estimator, sigma integration -- with the
+    reference's kernel parameters and 4x its runs reproduces sigma_tot / sigma_el / sigma_rxn to 5e-5 relative
+    (0.06 mb; the reference's own 8-run scatter is ~0.01 mb) and the printed head of its S_AB table.  c is not
+    recorded with the output; it is inferred (tests/golden/reference_c12_notebook.json, tools/run_c12_sweep.sh)."""
+    import ctypes as C
+    import json
+    from mcmc_amd import api, lib as L
+    ref = json.load(open(os.path.join(GOLD, "reference_c12_notebook.json")))
+    cfg = L.Config()
+    L.lib.mcmc_config_default(C.byref(cfg))
+    cfg.nNeutronA = cfg.nProtonA = cfg.nNeutronB = cfg.nProtonB = 6
+    ws = L.Target(L.TARGET_R2WS, ref["c_inferred"], 0.54)
+    cfg.neutronA = cfg.protonA = cfg.neutronB = cfg.protonB = ws
+    cfg.totalBlocks, cfg.threadsPerBlock, cfg.samplesPerThread, cfg.totalRuns = 64, 128, 64, 32
+    cfg.samplesForMix, cfg.b0, cfg.db, cfg.ndbs = 8192, 0.05, 0.1, 200
+    cfg.stepsize, cfg.sigmaNN, cfg.beta = 2.2, 4.3, 0.2
+    cfg.accept_rule, cfg.math_mode = L.ACCEPT_RECIP, L.MATH_FAST
+    h = C.c_void_p()
+    L.check(L.lib.mcmc_create(C.byref(cfg), C.byref(h)))
+    try:
+        L.check(L.lib.mcmc_warmup(h, cfg.stepsize, cfg.samplesForMix))
+        n = cfg.ndbs
+        b, S, E = (C.c_float * n)(), (C.c_float * n)(), (C.c_float * n)()
+        L.check(L.lib.mcmc_run_sab_scan(h, b, S, E, None, 0.0))
+    finally:
+        L.check(L.lib.mcmc_destroy(h))
+    b, S, E = (np.array(x[:], dtype=np.float64) for x in (b, S, E))
+    cs = api.CrossSections(b, S, E)
+    for key, name in (("tot", "sigma_tot_mb"), ("el", "sigma_el_mb"), ("rxn", "sigma_rxn_mb")):
+        assert abs(cs[key][0] - ref[name][0]) < 0.06, (key, cs[key], ref[name])
+    head = ref["S_AB_head"]
+    for i in range(5):
+        assert b[i] == pytest.approx(head["b"][i], abs=1e-6)
+        tol = 4 * np.hypot(head["S_AB_stderr"][i], E[i]) + 0.5e-6       # the notebook prints 6 decimals
+        assert abs(S[i] - head["S_AB"][i]) < tol, (i, S[i], head["S_AB"][i], tol)
+    assert S[195] == pytest.approx(ref["S_AB_tail"]["S_AB"], abs=1e-6)
