@@ -187,3 +187,35 @@ def test_live_reference_fresh_draws(oracle):
         assert oracle.variance_f64(s) == ref.variance(s)
         for k in (1, 10, 49):
             assert oracle.autocorrelation_f64(s, k) == ref.autocorrelation(s, k)
+
+
+def test_a12_oracle_against_the_reference_validated_sab_table(oracle):
+    """Estimate-level anchor of the a5-a12 RESTATEMENT: tests/golden/c12_sab_table_device.csv is the C-12 + C-12
+    S_AB(b) table whose cross sections agree with the ones the reference recorded (XSectionAnalysis.ipynb cell 5,
+    tests/golden/reference_c12_notebook.json) to 2e-5.  The oracle's chains + S_AB estimator, driven by numpy draws,
+    must give the same S_AB in the transition region within 4 standard errors (thread-to-thread scatter)."""
+    import oracle_lib as O
+    table = np.genfromtxt(os.path.join(GOLD, "c12_sab_table_device.csv"), delimiter=",", names=True)
+    nA = nB = 12
+    nN = nA + nB
+    targets = [(O.R2WS, 1.5555555556, 0.54)] * nN
+    threads, warm, samples, step = 48, 300, 1500, 2.2
+    rng = np.random.default_rng(12)
+    for idx in (30, 45, 60):                                   # b = 3.05, 4.55, 6.05 fm: S_AB ~ 0.3 .. 0.96
+        b = float(table["b"][idx])
+        means = []
+        for _ in range(threads):
+            dw = np.empty((warm, nN, 2), dtype=np.float32)
+            dw[:, :, 0] = rng.standard_normal((warm, nN))
+            dw[:, :, 1] = 1.0 - rng.random((warm, nN))
+            x, _ = oracle.warmup_thread(targets, [1.0] * nN, step, warm, dw)
+            d = np.empty((samples, 2, nN, 2), dtype=np.float32)
+            d[:, 0, :, 0] = rng.standard_normal((samples, nN))
+            d[:, 0, :, 1] = 1.0 - rng.random((samples, nN))
+            d[:, 1, :, :] = 1.0 - rng.random((samples, nN, 2))
+            _, m, _, _ = oracle.integrate_sab_thread(nA, nB, targets, x, step, samples, b, d)
+            means.append(m)
+        means = np.array(means, dtype=np.float64)
+        se = means.std(ddof=1) / np.sqrt(threads)
+        assert abs(means.mean() - table["S_AB"][idx]) < 4 * se + 1e-4, (b, means.mean(), table["S_AB"][idx], se)
+        assert se < 0.01
