@@ -14,8 +14,12 @@
  *     tests/test_oracle_pinning.py and tests/golden/.
  *   - xsection path (a5-a15): the .cuh files need the CUDA toolkit and cannot
  *     be built here; the reference holds no golden vectors for them, so these
- *     functions are a line-by-line restatement pinned only by closed-form /
- *     quadrature known answers ("parity unpinned" against reference outputs).
+ *     functions are a line-by-line restatement.  Draw-level parity is unpinned
+ *     against reference outputs ("parity unpinned"); at the level of estimates
+ *     they are anchored on the one output the reference records (the C-12 + C-12
+ *     cross sections and S_AB table in xsection/tools/XSectionAnalysis.ipynb,
+ *     tests/golden/reference_c12_notebook.json, with the Woods-Saxon radius
+ *     inferred) and on closed-form / quadrature known answers.
  *   - Philox4x32-10: third-party published algorithm (Salmon et al., SC'11,
  *     Random123 v1.09), pinned by Random123's known-answer vectors.
  *   - sigma analysis (f1): pinned against xsection/tools/XSectionAnalysis.py

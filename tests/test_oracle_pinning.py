@@ -8,7 +8,8 @@
   * Philox4x32-10: Random123 known-answer vectors (third-party published algorithm).
   * xsection path (a5-a15): the reference holds no vectors and its .cuh files need
     the CUDA toolkit, so these are regression vectors of the restatement plus
-    closed-form / quadrature known answers ("parity unpinned" vs reference outputs).
+    closed-form / quadrature known answers ("parity unpinned" vs reference outputs at the level of
+    draws); at the level of estimates: the reference's recorded C-12 + C-12 output (last test).
 """
 import os
 
