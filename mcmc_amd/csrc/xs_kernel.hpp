@@ -470,25 +470,26 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         }
         float prod = 1.0f;
         uint32_t ncoll = 0;
-        for (uint32_t q0 = 0; q0 < JB;) {
-            const uint32_t rem = JB - q0;
-            if (rem >= 16) {
-                sab_pairs<16, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
-                q0 += 16;
-            } else if (rem >= 8) {
-                sab_pairs<8, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
-                q0 += 8;
-            } else if (rem >= 4) {
-                sab_pairs<4, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
-                q0 += 4;
-            } else if (rem >= 2) {
-                sab_pairs<2, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
-                q0 += 2;
-            } else {
-                sab_pairs<1, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
-                q0 += 1;
-            }
-        }
+        // B slices of the lane in passes of 1, 2, 4, 8 (the binary digits of JB, smallest first), then 16s.
+        // Product only, one event per wavefront: once the product over the pairs done so far has underflowed
+        // to exactly 0 the remaining factors (all finite) cannot change it -- central heavy-ion events stop
+        // after the small passes (Pb-Pb: 2 + 8 of 26 slices).
+        constexpr bool EXIT0 = PROD && !HITS && G == 64;
+        uint32_t q0 = 0;
+        bool dead = false;
+        auto pass = [&](auto jc_tag) __attribute__((always_inline)) {
+            constexpr int JC = decltype(jc_tag)::value;
+            if (dead) return;
+            sab_pairs<JC, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
+            q0 += JC;
+            if constexpr (EXIT0) dead = q0 < JB && group_prod<G>(prod) == 0.0f;
+        };
+        if (JB & 1u) pass(std::integral_constant<int, 1>{});
+        if (JB & 2u) pass(std::integral_constant<int, 2>{});
+        if (JB & 4u) pass(std::integral_constant<int, 4>{});
+        if (JB & 8u) pass(std::integral_constant<int, 8>{});
+        while (q0 < JB && !dead) pass(std::integral_constant<int, 16>{});
+        if (dead) prod = 0.0f;
         if constexpr (PROD) {
             float y = group_prod<G>(prod);
             // Kahan, IntegrateSAB.cuh:81-85 (every lane of the group carries the same sum)
