@@ -381,3 +381,29 @@ def test_glauber_scan_event_sharding_is_exact(dev):
         if not inel_only:
             assert res["S_AB"][0] < res["S_AB"][1] < res["S_AB"][2] < res["S_AB"][3] and res["S_AB"][3] > 0.98
             assert res["sigma"]["rxn"][0] > 0
+
+
+@pytest.mark.parametrize("b", [0.0, 9.0, 13.0])
+def test_sab_zero_product_exit_changes_nothing(dev, b):
+    """Product-only S_AB for Pb-Pb stops an event's pair scan once its product has underflowed to 0; the kernel
+    with hit counters scans every pair.  Same events, same draws: per-event results agree to below the smallest
+    normal float (where the full scan ends on a denormal the early exit returns 0), chain states bit for bit."""
+    nA = nB = 208
+    PB = (O.R2WS, 6.62, 0.546)
+    T, samples = 40, 4
+    kw = dict(seed=777, sigmaNN=6.76)
+    e1 = _xs(dev, nA, nB, T, [PB] * 416, "nodiv_fast", **kw)
+    e3 = _xs(dev, nA, nB, T, [PB] * 416, "nodiv_fast", **kw)
+    for e in (e1, e3):
+        e.InitSampleFromPdf()
+        e.WarmupMetropolis(16, stepsize=3.9)
+    r1, _, _ = e1.MCIntegrate_S_AB(samples, b, stepsize=3.9)
+    r3, _, hits = e3.MCIntegrate_S_AB(samples, b, stepsize=3.9, dmax2=6.76 / np.pi)
+    torch.cuda.synchronize()
+    a, c = r1.cpu().numpy(), r3.cpu().numpy()
+    np.testing.assert_allclose(a, c, rtol=0, atol=1.2e-38)
+    assert torch.equal(e1.prevSample, e3.prevSample)
+    if b == 0.0:
+        assert np.all(a == 0.0)
+    if b == 13.0:
+        assert a.max() > 0.01 and np.array_equal(a, c)
