@@ -82,7 +82,9 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
         uint32_t row = p.ring_row0; // t mod lag, carried instead of a 64-bit modulo per sweep
         for (uint64_t t = ta; t < tb; ++t) {
             const uint64_t n0 = t * D; // index of this sweep's first proposal in the chain's draw stream
-            float xm = 0.0f, xc = xs[tid];
+            // the right neighbour is fetched from LDS one proposal ahead (xp for this proposal, xq for the next):
+            // with two waves per SIMD the LDS latency would otherwise sit on the serial chain of the sweep
+            float xm = 0.0f, xc = xs[tid], xp = xs[MVN_BLOCK + tid];
             float olm = 0.0f; // Q[i][i-1]
             for (uint32_t gi = 0; gi < D / 8; ++gi) {
                 const uint64_t g = (n0 >> 3) + gi;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
                         } else {
                             dz = p.step * z[h];
                         }
-                        const float xp = (i + 1 < D) ? xs[(i + 1) * MVN_BLOCK + tid] : 0.0f;
+                        const float xq = xs[(i + 2 < D ? i + 2 : D - 1) * MVN_BLOCK + tid]; // x_{i+2} (unused at the end: Q = 0)
                         const float qd = qd8[2 * J + h], orr = qo8[2 * J + h];
                         const float hsum = qd * xc + olm * xm + orr * xp;
                         const float t1 = hsum + qh8[2 * J + h] * dz;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
                         }
                         xm = xn;
                         xc = xp;
+                        xp = xq;
                         olm = orr;
                     }
                 };
