@@ -45,7 +45,62 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other kernels of the path")
     return ap.parse_args()
+
+
+def secondary(dev):
+    """Short runs of the other kernels of the path (outside the timed region; rank 0, N = 1 only): reported beside the
+    headline, never part of `value`.  tools/bench_xs.py, bench_mvn.py, bench_store.py are the full versions."""
+    import numpy as np
+    from mcmc_amd import api, lib as L
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return sorted(ts)[len(ts) // 2] * 1e-3
+
+    out = {}
+    try:
+        pb = (L.TARGET_R2WS, 6.62, 0.546)
+        T, ns = 1 << 14, 16
+        xs = api.XsEngine(208, 208, T, [pb] * 416, accept_rule=L.ACCEPT_CROSS, math_mode=L.MATH_FAST, sigmaNN=6.76, device=dev)
+        xs.InitSampleFromPdf()
+        xs.WarmupMetropolis(64, stepsize=3.9)
+        t = timed(lambda: xs.MCIntegrate_S_AB(ns, 13.0, stepsize=3.9))
+        out["sab_pbpb_b13_event_samples_per_s"] = T * ns / t
+        out["sab_pbpb_b13_pair_terms_per_s"] = T * ns * 208 * 208 / t
+        t = timed(lambda: xs.MCIntegrate_Inel(ns, 7.0, 6.76 / np.pi, stepsize=3.9))
+        out["inel_pbpb_b7_event_samples_per_s"] = T * ns / t
+        t = timed(lambda: xs.WarmupMetropolis(256, stepsize=3.9))
+        out["nucleon_chain_proposals_per_s"] = T * 416 * 256 / t
+        del xs
+        n, D, K = 1 << 21, 64, 32
+        qd, qo = api.ar1_precision(D, 0.9)
+        mv = api.MvnEngine(n, qd, qo, 0.8, 1000, math_mode=L.MATH_FAST, x0=0.0, device=dev)
+        obs = torch.empty((K, n), dtype=torch.float32, device=dev)
+        t = timed(lambda: mv.run(K, window=(0, 1 << 40), samples_obs=obs))
+        out["stress64_lag1000_proposals_per_s"] = n * D * K / t
+        out["stress64_lag1000_algorithmic_GBps"] = n * (K * 12 + 2 * 4 * D) / t / 1e9
+        del mv, obs
+        nc, C, S = 1 << 24, 3, 32
+        eng = api.ChainEngine(nc, C, api.make_target(L.TARGET_R2WS, 2.0, 0.54), 2.48, precision=32, accept_rule=L.ACCEPT_CROSS,
+                              math_mode=L.MATH_FAST, center=2.3, device=dev)
+        smp = torch.empty((S, C, nc), dtype=torch.float32, device=dev)
+        t = timed(lambda: eng.run(S, samples=smp))
+        out["chain_writeback_proposals_per_s"] = nc * C * S / t
+        out["chain_writeback_algorithmic_GBps"] = (nc * C * S * 4 + 2 * 4 * nc * C) / t / 1e9
+    except Exception as e:  # the headline line must not depend on these
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def cpu_baseline(args, seconds):
@@ -228,6 +283,8 @@ def main():
             out["ess_per_sec"] = value / tau
             out["tau_int"] = tau
             out["lag49_proposals_per_sec_per_gpu"] = sub * args.coords * 1024 / (ea.elapsed_time(eb) * 1e-3)
+    if rank == 0 and world == 1 and not args.no_secondary:
+        out["secondary"] = secondary(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         out["cpu_reference_f64"] = cpu_reference_f64(args.step_size)
