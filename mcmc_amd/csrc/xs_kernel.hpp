@@ -593,6 +593,85 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
 }
 
 // ---------------------------------------------------------------------
+// S_AB for light nuclei (NA, NB <= 4: the reference's own default He-4 + He-4, main.cu:38-41, and the
+// hydrogen / helium isotopes): one event per LANE with every nucleon in registers, as the reference does
+// (IntegrateSAB.cuh:30-78) -- no LDS, no barriers.  Same draws (tags 1 and 2, one Philox block per nucleon
+// and step pair and tag), same MH arithmetic and the same Kahan accumulation as sab_kernel, so the chain
+// states are bit-identical to the general kernel's and the per-event means agree to rounding (the pair
+// product is formed in the reference's i-major order here, per lane group there).
+// Product only, Philox draws, FAST math, r^2 Woods-Saxon densities; everything else takes sab_kernel.
+template <int NA, int NB, int RULE>
+__global__ __launch_bounds__(XS_BLOCK) void sab_small_kernel(const XsParams p)
+{
+    constexpr int NN = NA + NB;
+    constexpr int KIND = MCMC_TARGET_R2WS, MATH = MCMC_MATH_FAST;
+    const uint64_t e0 = (uint64_t)blockIdx.x * XS_BLOCK + threadIdx.x;
+    const bool valid = e0 < p.T;
+    const uint64_t e = valid ? e0 : p.T - 1; // lanes past the end replay the last event and store nothing
+    const uint64_t gid = p.event_offset + e;
+
+    TgtLds tgt[NN]; // wave-uniform: stays in scalar registers
+    float x[NN], aux[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+        const Target<float> t = make_target<float>(p.targets[n]);
+        tgt[n].p0 = t.p0, tgt[n].p1 = t.p1, tgt[n].k1 = t.k1, tgt[n].k0 = t.k0, tgt[n].kind = t.kind;
+        x[n] = p.prevSample[(uint64_t)n * p.T + e];
+        aux[n] = sab_aux_init<KIND, RULE, MATH>(tgt[n], x[n]);
+    }
+
+    float sum = 0.0f, err = 0.0f;
+    const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
+    if (p.samples > 0) {
+        for (uint64_t blk = ta >> 1; blk <= ((tb - 1) >> 1); ++blk) {
+            const uint64_t te = blk << 1;
+            const bool actA = te >= ta, actB = te + 1 < tb;
+            float2 trA[NN], trB[NN];
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                const u32x4 r = draw_block(p.seed, gid, (uint32_t)n, blk, TAG_SAB_MH);
+                float z0, z1;
+                box_muller<MATH>(r.x, r.y, z0, z1);
+                const u32x4 q = draw_block(p.seed, gid, (uint32_t)n, blk, TAG_ANGLE);
+                trA[n] = trB[n] = make_float2(0.0f, 0.0f);
+                if (actA) {
+                    sab_mh<KIND, RULE, MATH>(tgt[n], x[n], aux[n], p.stepsize, z0, u01(r.z));
+                    trA[n] = transverse<MATH>(x[n] * p.pos_scale, u01(q.x), u01(q.y));
+                    if (n < NA) trA[n].x = p.b_stored + trA[n].x;
+                }
+                if (actB) {
+                    sab_mh<KIND, RULE, MATH>(tgt[n], x[n], aux[n], p.stepsize, z1, u01(r.w));
+                    trB[n] = transverse<MATH>(x[n] * p.pos_scale, u01(q.z), u01(q.w));
+                    if (n < NA) trB[n].x = p.b_stored + trB[n].x;
+                }
+            }
+            auto product = [&](const float2 (&tr)[NN]) __attribute__((always_inline)) {
+                float y = 1.0f;
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) { // IntegrateSAB.cuh:66-78
+                        const float dx = tr[i].x - tr[NA + j].x, dy = tr[i].y - tr[NA + j].y;
+                        const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+                        y *= __builtin_fmaf(-p.G0, __builtin_amdgcn_exp2f(-d2), 1.0f);
+                    }
+                y -= err; // Kahan, IntegrateSAB.cuh:81-85
+                const float tt = sum + y;
+                err = (tt - sum) - y;
+                sum = tt;
+            };
+            if (actA) product(trA);
+            if (actB) product(trB);
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) p.prevSample[(uint64_t)n * p.T + e] = x[n];
+        p.result[e] = (sum - err) / p.samples; // IntegrateSAB.cuh:88
+    }
+}
+
+// ---------------------------------------------------------------------
 // Row reductions: out[row] = scale * sum(x[row][:]) in FP64, two fixed-order stages.
 constexpr int RR_CHUNKS = 64;
 

@@ -407,3 +407,52 @@ def test_sab_zero_product_exit_changes_nothing(dev, b):
         assert np.all(a == 0.0)
     if b == 13.0:
         assert a.max() > 0.01 and np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("mode", ["recip_fast", "nodiv_fast"])
+@pytest.mark.parametrize("nA,nB", [(4, 4), (1, 1), (2, 3), (4, 1), (3, 4)])
+def test_sab_light_nuclei_register_kernel_equals_general_kernel(dev, mode, nA, nB, monkeypatch):
+    """Light nuclei (<= 4 + 4 nucleons, the reference's default He-4 + He-4) take a kernel with one event per lane and
+    the nucleons in registers.  Same draws and step arithmetic as the general LDS kernel: chain states bit-identical,
+    per-event S_AB means equal to rounding (the product is formed in a different order), for a ragged event count,
+    an odd number of samples and a launch that starts on an odd sweep."""
+    nN = nA + nB
+    T, samples, b = 1000, 9, 1.3
+    tg = [WS20 if n % 2 == 0 else (O.R2WS, 1.7, 0.5) for n in range(nN)]
+    out = []
+    for small in ("1", "0"):
+        monkeypatch.setenv("MCMC_SAB_SMALL", small)
+        e = _xs(dev, nA, nB, T, tg, mode, seed=31, event_offset=12345)
+        e.WarmupMetropolis(5, stepsize=2.2)
+        r1, m1, _ = e.MCIntegrate_S_AB(samples, b)
+        r1 = r1.clone()
+        r2, m2, _ = e.MCIntegrate_S_AB(4, b + 0.5)
+        torch.cuda.synchronize()
+        out.append((r1.cpu().numpy(), r2.cpu().numpy().copy(), e.prevSample.cpu().numpy().copy(), m2.item()))
+    (a1, a2, sa, ma), (g1, g2, sg, mg) = out
+    assert np.array_equal(sa, sg)
+    np.testing.assert_allclose(a1, g1, rtol=3e-6, atol=1e-7)
+    np.testing.assert_allclose(a2, g2, rtol=3e-6, atol=1e-7)
+    assert ma == pytest.approx(mg, rel=1e-6)
+    assert 0.0 < a1.mean() < 1.0
+
+
+def test_sab_light_nuclei_default_dispatch_is_result_neutral(dev, monkeypatch):
+    """Without the override the register kernel is taken from 2^17 events on (below that the general kernel is
+    faster); whichever runs, chain states are identical and the integral agrees to rounding."""
+    T = 1 << 17
+    out = []
+    for small in (None, "0"):
+        if small is None:
+            monkeypatch.delenv("MCMC_SAB_SMALL", raising=False)
+        else:
+            monkeypatch.setenv("MCMC_SAB_SMALL", small)
+        e = _xs(dev, 4, 4, T, [WS20] * 8, "recip_fast", seed=5)
+        e.WarmupMetropolis(4, stepsize=2.2)
+        r, m, _ = e.MCIntegrate_S_AB(8, 2.0)
+        torch.cuda.synchronize()
+        out.append((r.cpu().numpy().copy(), e.prevSample.cpu().numpy().copy(), m.item()))
+    (a, sa, ma), (g, sg, mg) = out
+    assert np.array_equal(sa, sg)
+    np.testing.assert_allclose(a, g, rtol=3e-6, atol=1e-7)
+    assert ma == pytest.approx(mg, rel=1e-6)
