@@ -174,6 +174,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    trace_on = os.environ.get("MCMC_BENCH_TRACE") == "1"
+
+    def trace(msg):
+        if trace_on:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    trace("process group up")
     from mcmc_amd import api, dist as D, lib as L
     rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "log": L.ACCEPT_LOG, "cross": L.ACCEPT_CROSS}[args.rule]
     math = L.MATH_FAST if args.math == "fast" else L.MATH_PRECISE
@@ -193,9 +200,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace("engine created")
     for _ in range(args.warmup):
         step()
+    trace("warm-up steps queued")
     fence()
+    trace("fence passed")
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -205,6 +215,7 @@ def main():
         D.allreduce_stats(st)
     fence()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+    trace(f"timed region done: {elapsed:.3f} s")
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
 
     proposals_per_step = world * args.chains * args.coords * args.sweeps

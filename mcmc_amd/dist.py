@@ -24,6 +24,17 @@ def partition(n_total, rank, world):
     return offset, count
 
 
+def _all_reduce(t, op, group=None):
+    """all_reduce of a device tensor; `gloo` (CPU tests, one-GPU rehearsals) gets a host copy, RCCL the tensor itself."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def allreduce_stats(stats, n_lags=None, group=None):
     """Sum a [n_coords][MCMC_STATS_LEN] (or any) float64 statistics tensor over ranks, in place.
     A no-op when torch.distributed is not initialised (single GPU).  Every entry of the vector is a
@@ -32,7 +43,7 @@ def allreduce_stats(stats, n_lags=None, group=None):
     if stats.dtype != torch.float64:
         raise TypeError("sufficient statistics are reduced in float64")
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(stats, dist.ReduceOp.SUM, group)
     return stats
 
 
@@ -41,7 +52,7 @@ def max_over_ranks(seconds, device=None, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(seconds)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(t, dist.ReduceOp.MAX, group)
     return float(t.item())
 
 
