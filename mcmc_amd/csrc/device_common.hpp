@@ -442,6 +442,20 @@ __device__ __forceinline__ float group_prod(float v)
     return v;
 }
 
+// Minimum / maximum over all 64 lanes; every lane receives the result.
+__device__ __forceinline__ float wave_minf(float v)
+{
+    v = __builtin_fminf(v, dpp_f32<DPP_QUAD_XOR1>(v));
+    v = __builtin_fminf(v, dpp_f32<DPP_QUAD_XOR2>(v));
+    v = __builtin_fminf(v, dpp_f32<DPP_ROW_HALF_MIRROR>(v));
+    v = __builtin_fminf(v, dpp_f32<DPP_ROW_MIRROR>(v));
+    v = __builtin_fminf(v, __shfl_xor(v, 16, 64));
+    v = __builtin_fminf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+__device__ __forceinline__ float wave_maxf(float v) { return -wave_minf(-v); }
+
 // c + (h ? 1 : 0) as ONE VALU op: the compare result stays a lane mask in SGPRs and enters
 // v_addc_co_u32 as the carry (hipcc otherwise materialises 0/1 with v_cndmask and adds).
 __device__ __forceinline__ uint32_t count_if(uint32_t c, bool h)

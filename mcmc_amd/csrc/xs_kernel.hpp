@@ -32,6 +32,7 @@ struct XsParams {
     float b_stored;        // impact parameter in the units of the stored transverse positions
     float pos_scale;       // FAST: sqrt(log2(e) / (2 beta)), so that Gamma = G0 * 2^(-d'^2); PRECISE: 1
     float hit_d2;          // black-disk dmax^2 in the same units
+    float cull_d;          // > 0: pairs farther apart than this (same units) change nothing (see sab_cull); 0: off
     uint32_t ga_log2;      // the G lanes of an event form a (1 << ga_log2) x (G >> ga_log2) grid over A x B
     const mcmc_target *targets;
     float *prevSample;
@@ -282,15 +283,18 @@ __device__ __forceinline__ float2 transverse(float r, float u0, float u1)
 // the stored positions are pre-multiplied by sqrt(log2(e)/(2 beta)), so a pair costs
 // 2 sub + mul + fma + v_exp_f32 + fma + mul.
 template <int JC, int MATH, bool PROD, bool HITS>
-__device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, uint32_t *partE, uint32_t la, uint32_t lb,
-                                          uint32_t GA, uint32_t GB, uint32_t q0, float &prod, uint32_t &ncoll)
+__device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, uint32_t *partE, uint32_t nAe, uint32_t nBe,
+                                          uint32_t la, uint32_t lb, uint32_t GA, uint32_t GB, uint32_t q0, float &prod,
+                                          uint32_t &ncoll)
 {
+    // nAe / nBe: the A nucleons trE[0 .. nAe) and B nucleons trE[p.nA .. p.nA + nBe) that take part (all of them,
+    // or what sab_cull kept)
     float bx[JC], by[JC], pr[JC];
     uint32_t cq[JC]; // HITS: collisions of B nucleon q (per-q counters double as the participant flags)
 #pragma unroll
     for (int q = 0; q < JC; ++q) {
         const uint32_t j = lb + (q0 + q) * GB;
-        const bool ok = j < p.nB;
+        const bool ok = j < nBe;
         const float2 v = trE[p.nA + (ok ? j : 0)];
         bx[q] = ok ? v.x : 1.0e30f; // d^2 = inf -> Gamma = 0 -> factor exactly 1, never a hit
         by[q] = ok ? v.y : 0.0f;
@@ -298,11 +302,11 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
         cq[q] = 0u;
     }
     uint32_t i = la;
-    if (i < p.nA) {
+    if (i < nAe) {
         float2 a = trE[i];
         for (;;) {
             const uint32_t in = i + GA;
-            const bool more = in < p.nA;
+            const bool more = in < nAe;
             const float2 an = trE[more ? in : i];
             float dmin = __builtin_inff(); // HITS: nearest of this lane's B nucleons to A nucleon i
 #pragma unroll
@@ -347,25 +351,25 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
 // returns true as soon as `ballot(dmin < hit_d2)` is non-zero.  For central heavy-ion events that is the
 // first iteration.
 template <int JC, int G, int MATH>
-__device__ __forceinline__ bool sab_pairs_inel(const XsParams &p, const float2 *trE, uint32_t la, uint32_t lb, uint32_t GA,
-                                               uint32_t GB, uint32_t q0, float &dmin)
+__device__ __forceinline__ bool sab_pairs_inel(const XsParams &p, const float2 *trE, uint32_t nAe, uint32_t nBe, uint32_t la,
+                                               uint32_t lb, uint32_t GA, uint32_t GB, uint32_t q0, float &dmin)
 {
     float bx[JC], by[JC];
 #pragma unroll
     for (int q = 0; q < JC; ++q) {
         const uint32_t j = lb + (q0 + q) * GB;
-        const bool ok = j < p.nB;
+        const bool ok = j < nBe;
         const float2 v = trE[p.nA + (ok ? j : 0)];
         bx[q] = ok ? v.x : 1.0e30f;
         by[q] = ok ? v.y : 0.0f;
     }
-    const uint32_t KA = (p.nA + GA - 1) >> p.ga_log2;
-    const bool ok0 = la < p.nA;
+    const uint32_t KA = (nAe + GA - 1) >> p.ga_log2;
+    const bool ok0 = la < nAe;
     float2 a = trE[ok0 ? la : 0];
     if (!ok0) a = make_float2(-1.0e30f, 0.0f);
     for (uint32_t k = 0; k < KA; ++k) {
         const uint32_t in = la + GA * (k + 1);
-        const bool more = in < p.nA;
+        const bool more = in < nAe;
         float2 an = trE[more ? in : 0];
         if (!more) an = make_float2(-1.0e30f, 0.0f);
 #pragma unroll
@@ -445,22 +449,89 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     float sum = 0.0f, err = 0.0f;
     uint32_t h_coll = 0, h_inel = 0, h_part = 0;
     const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
-    const uint32_t JB = (p.nB + GB - 1) / GB;
 
-    auto pair_sweep = [&](const float2 *trE) {
+    // Exact pair culling (one event per wavefront).  A pair farther apart than cull_d contributes the factor
+    // exactly 1.0f (Gamma <= 2^-25 is absorbed by the rounding of 1 - Gamma, in the reference's arithmetic too)
+    // and is never a black-disk hit, so an A nucleon outside the bounding box of B grown by cull_d -- and then a
+    // B nucleon outside the grown box of the A nucleons kept -- can be dropped without changing any result bit
+    // beyond the order of the multiplications.  The survivors are compacted in place (ballot prefix sums); the
+    // pair tile then runs over nAe x nBe nucleons: peripheral collisions, where the zero-product exit never
+    // fires, keep only the overlap strip.  Culling costs about 1000 issue cycles per sample, so it is skipped
+    // where it cannot pay: for good once a sample keeps more than 7/8 of the pairs; in the product-only mode
+    // while the previous sample of the event ended in an early zero-product exit; and in the inelastic-only
+    // mode a short probe of the unculled nucleons comes first (central events collide there and are done).
+    uint32_t nAe = p.nA, nBe = p.nB;
+    bool cull_on = G == 64 && p.cull_d > 0.0f;
+    bool cull_next = true;
+    auto cull_side = [&](float2 *v0, uint32_t n0, float x0, float x1, float y0, float y1, float &kx0, float &kx1,
+                         float &ky0, float &ky1) -> uint32_t {
+        uint32_t cnt = 0;
+        kx0 = ky0 = __builtin_inff();
+        kx1 = ky1 = -__builtin_inff();
+        for (uint32_t base = 0; base < n0; base += 64) {
+            const uint32_t n = base + (uint32_t)lg;
+            const bool ok = n < n0;
+            const float2 v = v0[ok ? n : 0];
+            const bool keep = ok && v.x >= x0 && v.x <= x1 && v.y >= y0 && v.y <= y1;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (keep) {
+                v0[pos] = v; // pos <= n, and every lane has read its element of this round already
+                kx0 = __builtin_fminf(kx0, v.x);
+                kx1 = __builtin_fmaxf(kx1, v.x);
+                ky0 = __builtin_fminf(ky0, v.y);
+                ky1 = __builtin_fmaxf(ky1, v.y);
+            }
+            cnt += (uint32_t)__builtin_popcountll(m);
+        }
+        return cnt;
+    };
+    auto sab_cull = [&](float2 *trE) {
+        if constexpr (G == 64) {
+            const float inf = __builtin_inff();
+            float bx0 = inf, bx1 = -inf, by0 = inf, by1 = -inf;
+            for (uint32_t n = p.nA + (uint32_t)lg; n < nN; n += 64) {
+                const float2 v = trE[n];
+                bx0 = __builtin_fminf(bx0, v.x);
+                bx1 = __builtin_fmaxf(bx1, v.x);
+                by0 = __builtin_fminf(by0, v.y);
+                by1 = __builtin_fmaxf(by1, v.y);
+            }
+            const float cd = p.cull_d;
+            float ax0, ax1, ay0, ay1, t0, t1, t2, t3;
+            nAe = cull_side(trE, p.nA, wave_minf(bx0) - cd, wave_maxf(bx1) + cd, wave_minf(by0) - cd, wave_maxf(by1) + cd, ax0,
+                            ax1, ay0, ay1);
+            nBe = cull_side(trE + p.nA, p.nB, wave_minf(ax0) - cd, wave_maxf(ax1) + cd, wave_minf(ay0) - cd,
+                            wave_maxf(ay1) + cd, t0, t1, t2, t3);
+            if ((uint64_t)nAe * nBe * 8u > (uint64_t)p.nA * p.nB * 7u) cull_on = false;
+        }
+    };
+
+    auto pair_sweep = [&](float2 *trE) {
+        nAe = p.nA;
+        nBe = p.nB;
         if constexpr (INEL) {
             float dmin = __builtin_inff();
             bool hit = false;
+            if constexpr (G == 64) {
+                if (cull_on) {
+                    // probe: the first two A nucleons of every lane against its first 16 B nucleons
+                    const uint32_t nAp = 2u * GA < p.nA ? 2u * GA : p.nA;
+                    hit = sab_pairs_inel<16, G, MATH>(p, trE, nAp, p.nB, la, lb, GA, GB, 0u, dmin);
+                    if (!hit) sab_cull(trE);
+                }
+            }
+            const uint32_t JB = (nBe + GB - 1) / GB;
             for (uint32_t q0 = 0; q0 < JB && !hit;) {
                 const uint32_t rem = JB - q0;
                 if (rem >= 16) {
-                    hit = sab_pairs_inel<16, G, MATH>(p, trE, la, lb, GA, GB, q0, dmin);
+                    hit = sab_pairs_inel<16, G, MATH>(p, trE, nAe, nBe, la, lb, GA, GB, q0, dmin);
                     q0 += 16;
                 } else if (rem >= 4) {
-                    hit = sab_pairs_inel<4, G, MATH>(p, trE, la, lb, GA, GB, q0, dmin);
+                    hit = sab_pairs_inel<4, G, MATH>(p, trE, nAe, nBe, la, lb, GA, GB, q0, dmin);
                     q0 += 4;
                 } else {
-                    hit = sab_pairs_inel<1, G, MATH>(p, trE, la, lb, GA, GB, q0, dmin);
+                    hit = sab_pairs_inel<1, G, MATH>(p, trE, nAe, nBe, la, lb, GA, GB, q0, dmin);
                     q0 += 1;
                 }
             }
@@ -468,19 +539,21 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
             h_inel += hit ? 1u : 0u;
             return;
         }
+        constexpr bool EXIT0 = PROD && !HITS && G == 64;
+        if (cull_on && (cull_next || !EXIT0)) sab_cull(trE);
+        const uint32_t JB = (nBe + GB - 1) / GB;
         float prod = 1.0f;
         uint32_t ncoll = 0;
         // B slices of the lane in passes of 1, 2, 4, 8 (the binary digits of JB, smallest first), then 16s.
         // Product only, one event per wavefront: once the product over the pairs done so far has underflowed
         // to exactly 0 the remaining factors (all finite) cannot change it -- central heavy-ion events stop
         // after the small passes (Pb-Pb: 2 + 8 of 26 slices).
-        constexpr bool EXIT0 = PROD && !HITS && G == 64;
         uint32_t q0 = 0;
         bool dead = false;
         auto pass = [&](auto jc_tag) __attribute__((always_inline)) {
             constexpr int JC = decltype(jc_tag)::value;
             if (dead) return;
-            sab_pairs<JC, MATH, PROD, HITS>(p, trE, partE, la, lb, GA, GB, q0, prod, ncoll);
+            sab_pairs<JC, MATH, PROD, HITS>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll);
             q0 += JC;
             if constexpr (EXIT0) dead = q0 < JB && group_prod<G>(prod) == 0.0f;
         };
@@ -490,6 +563,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         if (JB & 8u) pass(std::integral_constant<int, 8>{});
         while (q0 < JB && !dead) pass(std::integral_constant<int, 16>{});
         if (dead) prod = 0.0f;
+        if constexpr (EXIT0) cull_next = !(dead && 2u * q0 <= JB);
         if constexpr (PROD) {
             float y = group_prod<G>(prod);
             // Kahan, IntegrateSAB.cuh:81-85 (every lane of the group carries the same sum)

@@ -2,6 +2,7 @@
 // selection and launches for InitSampleArray / WarmupMetropolis /
 // MCIntegrate_R2 / MCIntegrate_S_AB (xsection/src/main.cu:130-149,197,335) and
 // the device row means that replace the host Average of main.cu:221-223,359.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -190,6 +191,27 @@ int launch_sab_mode(const mcmc_xs_args *a, const XsParams &p, const SabPlan &pla
     }
 }
 
+// Distance, in the units of the stored positions, beyond which a nucleon pair changes no result (sab_cull in
+// xs_kernel.hpp).  Product: 1 - Gamma rounds to exactly 1.0f once |Gamma| <= 2^-25, i.e. once
+// d^2 / (2 beta) * log2(e) >= 25 + log2|G0|; 0.05 on that exponent (3.5 % on Gamma) covers the error of
+// v_exp_f32 / expf and of the coordinate differences by orders of magnitude.  Hits: d^2 < dmax2 is impossible
+// beyond sqrt(dmax2) (0.1 % of margin).  MCMC_SAB_CULL=0 switches the culling off (tests compare the two).
+float sab_cull_distance(const mcmc_xs_args *a, const XsParams &p, bool prod, bool hit)
+{
+    const char *ov = std::getenv("MCMC_SAB_CULL");
+    if (ov && ov[0] == '0') return 0.0f;
+    double c2 = 0.0;
+    if (prod) {
+        if (!(std::fabs((double)p.G0) > 0.0) || !std::isfinite((double)p.G0)) return 0.0f;
+        double sexp = 25.05 + std::log2(std::fabs((double)p.G0));
+        if (sexp < 0.0) sexp = 0.0;
+        c2 = a->math_mode == MCMC_MATH_FAST ? sexp : sexp * 0.6931471805599453 * (double)p.twoBeta;
+    }
+    if (hit && (double)p.hit_d2 * 1.001 > c2) c2 = (double)p.hit_d2 * 1.001;
+    if (!(c2 > 0.0) || !std::isfinite(c2)) return 0.0f;
+    return (float)(std::sqrt(c2) * 1.0005);
+}
+
 // Register-resident kernel for light nuclei (sab_small_kernel): NA, NB in 1..4.
 template <int NA, int NB>
 int launch_sab_small_ab(const mcmc_xs_args *a, const XsParams &p, hipStream_t s)
@@ -339,6 +361,7 @@ extern "C" int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuf
     const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB, hits != nullptr);
     if (plan.lds > 160 * 1024) return set_error(MCMC_EINVAL, "nuclei too large for the LDS-resident S_AB kernel (A+B <= ~1600)");
     p.ga_log2 = (uint32_t)plan.ga_log2;
+    p.cull_d = sab_cull_distance(a, p, resultBuffer != nullptr, hits != nullptr);
     if (sab_small_applies(a, resultBuffer && !hits)) rc = launch_sab_small(a, p, s);
     else if (resultBuffer && hits) rc = launch_sab_mode<3>(a, p, plan, all_r2ws, s);
     else if (resultBuffer) rc = launch_sab_mode<1>(a, p, plan, all_r2ws, s);
@@ -385,6 +408,7 @@ extern "C" int mcmc_launch_integrate_inel(const mcmc_xs_args *a, uint32_t sample
     const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB, false);
     if (plan.lds > 160 * 1024) return set_error(MCMC_EINVAL, "nuclei too large for the LDS-resident S_AB kernel (A+B <= ~1600)");
     p.ga_log2 = (uint32_t)plan.ga_log2;
+    p.cull_d = sab_cull_distance(a, p, false, true);
     rc = launch_sab_mode<4>(a, p, plan, a->uniform_kind == MCMC_TARGET_R2WS, s);
     if (rc) return rc;
     rc = row_reduce<uint32_t>(hitbuf, 1, a->totalThreads, 1.0, hits2, 0, a->workspace, a->workspace_bytes, s);

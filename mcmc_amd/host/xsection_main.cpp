@@ -205,7 +205,7 @@ int main(int argc, char **argv)
         t0 = now();
         if (mcmc_run_sab_scan(h, b.data(), S.data(), E.data(), blackDisk ? pin.data() : nullptr, dmax2)) die("mcmc_run_sab_scan");
         const double t = ms(t0, now());
-        std::printf("S_AB scan: %d impact parameters in %.1f ms (%.3g event samples/s, %.3g pair terms/s)\n", n, t,
+        std::printf("S_AB scan: %d impact parameters in %.1f ms (%.3g event samples/s, %.3g nominal pair terms/s)\n", n, t,
                     totalSamples * n / (t * 1e-3), totalSamples * n * nNucleonsA * nNucleonsB / (t * 1e-3));
         if (!mcmc_host::write_sab_csv(b, S, E, blackDisk ? &pin : nullptr, outDir + outFile + ".S_AB.csv")) {
             std::fprintf(stderr, "xsection: cannot write %s%s.S_AB.csv\n", outDir.c_str(), outFile.c_str());

@@ -456,3 +456,45 @@ def test_sab_light_nuclei_default_dispatch_is_result_neutral(dev, monkeypatch):
     assert np.array_equal(sa, sg)
     np.testing.assert_allclose(a, g, rtol=3e-6, atol=1e-7)
     assert ma == pytest.approx(mg, rel=1e-6)
+
+
+PB = (O.R2WS, 6.62, 0.546)
+
+
+@pytest.mark.parametrize("nA,nB,b", [(208, 208, 0.0), (208, 208, 9.0), (208, 208, 13.0), (208, 208, 17.0), (208, 208, 40.0),
+                                     (197, 63, 7.0), (63, 197, 11.0), (129, 40, 9.5)])
+@pytest.mark.parametrize("mode", ["recip_fast", "recip_precise"])
+def test_sab_exact_pair_culling_changes_nothing(dev, mode, nA, nB, b, monkeypatch):
+    """One event per wavefront: nucleons outside the other nucleus's bounding box grown by the distance at which
+    1 - Gamma rounds to exactly 1.0f (and beyond the black-disk radius) are dropped before the pair tile.  Against the
+    same launches with MCMC_SAB_CULL=0: chain states and every hit counter identical, the inelastic-only count
+    identical, per-event products equal to rounding (only the order of the multiplications differs) -- central,
+    peripheral, disjoint (b = 40 fm: product exactly 1, no hits) and asymmetric systems."""
+    nN = nA + nB
+    T, samples = 130, 5
+    dmax2 = 6.76 / np.pi
+    out = []
+    for cull in ("1", "0"):
+        monkeypatch.setenv("MCMC_SAB_CULL", cull)
+        e = _xs(dev, nA, nB, T, [PB] * nN, mode, seed=77)
+        e.InitSampleFromPdf()
+        e.WarmupMetropolis(6, stepsize=2.2)
+        r1, m1, _ = e.MCIntegrate_S_AB(samples, b)                      # product only
+        r1 = r1.cpu().numpy().copy()
+        r3, m3, h3 = e.MCIntegrate_S_AB(samples, b, dmax2=dmax2)        # product + hit counters
+        r3, h3 = r3.cpu().numpy().copy(), h3.cpu().numpy().copy()
+        h4 = e.MCIntegrate_Inel(samples, b, dmax2).cpu().numpy().copy()  # inelastic flag only
+        torch.cuda.synchronize()
+        out.append((r1, r3, h3, h4, e.prevSample.cpu().numpy().copy()))
+    (c1, c3, ch3, ch4, cs), (g1, g3, gh3, gh4, gs) = out
+    assert np.array_equal(cs, gs)
+    assert np.array_equal(ch3, gh3)
+    assert np.array_equal(ch4, gh4)
+    # a per-event mean is a sum of products of either sign (Gamma(0) > 1): rounding relative to the terms, not the sum
+    np.testing.assert_allclose(c1, g1, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(c3, g3, rtol=2e-5, atol=2e-7)
+    assert np.array_equal(c1 == 0.0, g1 == 0.0)
+    if b >= 40.0:
+        assert np.all(c1 == 1.0) and ch3[0] == 0 and ch4[0] == 0
+    if b == 13.0:
+        assert 0.0 < c1.mean() < 1.0 and ch3[0] > 0

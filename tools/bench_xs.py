@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--samples", type=int, default=16)
     ap.add_argument("--rule", default="recip")
     ap.add_argument("--which", default="c3,c4,he")
+    ap.add_argument("--bs", default="0,7,14", help="impact parameters (fm) of the Pb-Pb S_AB launches")
+    ap.add_argument("--inel-bs", default="0,7,14,18", help="impact parameters (fm) of the Pb-Pb inelastic-only launches")
     args = ap.parse_args()
     rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "cross": L.ACCEPT_CROSS}[args.rule]
     dev = torch.device("cuda:0")
@@ -61,7 +63,7 @@ def main():
         T = args.events
         xs = api.XsEngine(208, 208, T, [PB] * 416, accept_rule=rule, math_mode=L.MATH_FAST, sigmaNN=6.76, device=dev)
         xs.WarmupMetropolis(512, stepsize=2.2)
-        for b in (0.0, 7.0, 14.0):
+        for b in [float(v) for v in args.bs.split(",")]:
             ms = timed(lambda: xs.MCIntegrate_S_AB(args.samples, b, stepsize=2.2), args.reps)
             n = T * args.samples
             print(json.dumps({"kernel": "MCIntegrate_S_AB", "system": "Pb-208+Pb-208", "b": b, "events": T,
@@ -72,7 +74,7 @@ def main():
         print(json.dumps({"kernel": "MCIntegrate_S_AB+hits", "system": "Pb-208+Pb-208", "b": 7.0, "events": T,
                           "samples": args.samples, "ms": ms, "event_samples_per_s": n / (ms * 1e-3),
                           "pairs_per_s": n * 208 * 208 / (ms * 1e-3), "hits": xs.hits.cpu().tolist()}))
-        for b in (0.0, 7.0, 14.0, 18.0):
+        for b in [float(v) for v in args.inel_bs.split(",")]:
             ms = timed(lambda: xs.MCIntegrate_Inel(args.samples, b, 6.76 / 3.14159265, stepsize=2.2), args.reps)
             h = xs.hits.cpu().tolist()
             print(json.dumps({"kernel": "MCIntegrate_Inel", "system": "Pb-208+Pb-208", "b": b, "events": T,
