@@ -70,7 +70,7 @@ def test_warmup_and_r2_injected(dev, oracle, mode, nN):
 
 @pytest.mark.parametrize("mode", ["recip_precise", "recip_fast"])
 @pytest.mark.parametrize("nA,nB", [(2, 2), (4, 4), (3, 5), (12, 12), (16, 20), (70, 70), (208, 208), (197, 63)])
-@pytest.mark.parametrize("b", [0.0, 1.5])
+@pytest.mark.parametrize("b", [0.0, 1.5, 5.0])   # 5.0: nuclei that only graze -- the pair culling of G = 64 is active
 def test_sab_injected(dev, oracle, mode, nA, nB, b):
     """a12: per-thread Kahan mean of prod (1 - Gamma), plus black-disk hit counters."""
     nN = nA + nB
@@ -198,7 +198,7 @@ def test_layer_b_sab_scan_and_cross_sections(dev):
 
 @pytest.mark.parametrize("mode", ["recip_precise", "recip_fast"])
 @pytest.mark.parametrize("nA,nB", [(2, 2), (3, 5), (16, 20), (70, 70)])
-@pytest.mark.parametrize("b", [0.0, 3.0])
+@pytest.mark.parametrize("b", [0.0, 3.0, 5.0])
 def test_inel_injected(dev, oracle, mode, nA, nB, b):
     """Inelastic-flag-only kernel (mcmc_launch_integrate_inel): the count of samples with >= 1 black-disk
     collision equals the oracle's, the chains advance exactly as in MCIntegrate_S_AB, and the count is identical
