@@ -220,3 +220,19 @@ def test_a12_oracle_against_the_reference_validated_sab_table(oracle):
         se = means.std(ddof=1) / np.sqrt(threads)
         assert abs(means.mean() - table["S_AB"][idx]) < 4 * se + 1e-4, (b, means.mean(), table["S_AB"][idx], se)
         assert se < 0.01
+
+
+@pytest.mark.parametrize("sigmaNN,beta", [(4.3, 0.2), (6.76, 0.2), (4.3, 0.35), (0.5, 0.1)])
+def test_pair_culling_distance_is_exact_in_the_reference_arithmetic(oracle, sigmaNN, beta):
+    """The S_AB kernels drop pairs farther apart than d_c = sqrt((25.05 + log2 G0) * 2 beta ln 2) (xsection.hip,
+    sab_cull_distance).  In the reference's float arithmetic (IntegrateSAB.cuh:9-17, restated in the oracle) such a
+    pair contributes the factor exactly 1.0f: Gamma <= 2^-25 is absorbed by the rounding of 1 - Gamma.  Checked at
+    d_c^2, a little inside it (the margin), and far outside; and that the distance is not wastefully large."""
+    G0 = sigmaNN / (4 * 3.141592653589 * beta)
+    dc2 = (25.05 + np.log2(G0)) * 2 * beta * np.log(2.0)
+    for f in (0.9985, 1.0, 1.01, 2.0, 50.0):
+        g = np.float32(oracle.gamma_nn_r2(float(np.float32(dc2 * f)), sigmaNN, beta))
+        assert 0.0 <= g <= 2.0 ** -25, (f, g)
+        assert np.float32(1.0) - g == np.float32(1.0)
+    g_in = np.float32(oracle.gamma_nn_r2(float(np.float32(dc2 * 0.98)), sigmaNN, beta))
+    assert np.float32(1.0) - g_in < np.float32(1.0)       # 2 % closer the factor is no longer 1: d_c is tight
