@@ -539,7 +539,8 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
             h_inel += hit ? 1u : 0u;
             return;
         }
-        constexpr bool EXIT0 = PROD && !HITS && G == 64;
+        constexpr bool EXIT0 = PROD && !HITS && G == 64; // product only: a zero product ends the event sample
+        constexpr bool DROP0 = PROD && HITS && G == 64;  // with hit counters: a zero product ends the exp work only
         if (cull_on && (cull_next || !EXIT0)) sab_cull(trE);
         const uint32_t JB = (nBe + GB - 1) / GB;
         float prod = 1.0f;
@@ -547,21 +548,29 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         // B slices of the lane in passes of 1, 2, 4, 8 (the binary digits of JB, smallest first), then 16s.
         // Product only, one event per wavefront: once the product over the pairs done so far has underflowed
         // to exactly 0 the remaining factors (all finite) cannot change it -- central heavy-ion events stop
-        // after the small passes (Pb-Pb: 2 + 8 of 26 slices).
+        // after the small passes (Pb-Pb: 2 + 8 of 26 slices).  With hit counters every pair is still needed for
+        // the counts, but the remaining passes run without the product (no exp).
         uint32_t q0 = 0;
         bool dead = false;
         auto pass = [&](auto jc_tag) __attribute__((always_inline)) {
             constexpr int JC = decltype(jc_tag)::value;
-            if (dead) return;
-            sab_pairs<JC, MATH, PROD, HITS>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll);
+            if constexpr (DROP0) {
+                if (dead) sab_pairs<JC, MATH, false, true>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll);
+                else sab_pairs<JC, MATH, true, true>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll);
+            } else {
+                if (dead) return;
+                sab_pairs<JC, MATH, PROD, HITS>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll);
+            }
             q0 += JC;
-            if constexpr (EXIT0) dead = q0 < JB && group_prod<G>(prod) == 0.0f;
+            if constexpr (EXIT0 || DROP0) {
+                if (!dead) dead = q0 < JB && group_prod<G>(prod) == 0.0f;
+            }
         };
         if (JB & 1u) pass(std::integral_constant<int, 1>{});
         if (JB & 2u) pass(std::integral_constant<int, 2>{});
         if (JB & 4u) pass(std::integral_constant<int, 4>{});
         if (JB & 8u) pass(std::integral_constant<int, 8>{});
-        while (q0 < JB && !dead) pass(std::integral_constant<int, 16>{});
+        while (q0 < JB && !(dead && !DROP0)) pass(std::integral_constant<int, 16>{});
         if (dead) prod = 0.0f;
         if constexpr (EXIT0) cull_next = !(dead && 2u * q0 <= JB);
         if constexpr (PROD) {
