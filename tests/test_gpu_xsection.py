@@ -498,3 +498,30 @@ def test_sab_exact_pair_culling_changes_nothing(dev, mode, nA, nB, b, monkeypatc
         assert np.all(c1 == 1.0) and ch3[0] == 0 and ch4[0] == 0
     if b == 13.0:
         assert 0.0 < c1.mean() < 1.0 and ch3[0] > 0
+
+
+@pytest.mark.parametrize("nA,nB,b", [(208, 208, 9.0), (208, 208, 15.0), (12, 12, 2.0), (4, 4, 1.0)])
+def test_sab_hit_counters_without_the_product(dev, nA, nB, b):
+    """`mcmc_launch_integrate_sab` with a null resultBuffer (black-disk counters only, no exp): the counters and the
+    chain advance equal those of the product + counters launch on the same draws."""
+    from mcmc_amd import api, lib as L
+    nN, T, samples = nA + nB, 200, 7
+    dmax2 = 6.76 / np.pi
+    tg = [PB] * nN if nN > 100 else [WS20] * nN
+    out = []
+    for product in (True, False):
+        e = _xs(dev, nA, nB, T, tg, "recip_fast", seed=123)
+        e.InitSampleFromPdf()
+        e.WarmupMetropolis(5, stepsize=2.2)
+        if product:
+            _, _, h = e.MCIntegrate_S_AB(samples, b, dmax2=dmax2)
+        else:
+            L.check(L.lib.mcmc_launch_integrate_sab(C.byref(e.args), None, samples, C.c_float(b), None,
+                                                    C.c_void_p(e.hits.data_ptr()), C.c_float(dmax2), api._stream()))
+            h = e.hits
+        torch.cuda.synchronize()
+        out.append((h.cpu().numpy().copy(), e.prevSample.cpu().numpy().copy()))
+    (h3, s3), (h2, s2) = out
+    assert np.array_equal(h3, h2)
+    assert np.array_equal(s3, s2)
+    assert h3[3] == T * samples
