@@ -598,10 +598,23 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         h_part += group_sum_u32<G>(c);
     };
 
+    // Inelastic-only mode, one event per wavefront, Philox draws: the angles of a sample are fresh draws, not
+    // chain state, so they are only worked out for the nucleons a sweep actually looks at.  The MH loop leaves
+    // the radii in the position buffers; the probe subset (the first 2 GA nucleons of A, the first 4 GB of B)
+    // gets its angles (one Philox block per nucleon and step pair + sqrt/sin/cos) at once, the other nucleons
+    // only if a probe of this step pair finds no collision.  Counter-based draws: the positions are bit-identical
+    // to the eager evaluation, whichever nucleons are skipped.
+    // An event whose probe misses once (peripheral: the probe costs more than it saves) goes back to the eager
+    // evaluation for the rest of the launch.
+    constexpr bool LAZY = INEL && G == 64 && !INJ;
+    bool lazy_on = true;
+
     if (p.samples > 0) {
         for (uint64_t blk = ta >> 1; blk <= ((tb - 1) >> 1); ++blk) {
             const uint64_t te = blk << 1;
             const bool actA = te >= ta, actB = te + 1 < tb;
+            bool lazy = false, needA = actA, needB = actB; // need*: the sweep is still to be done by pair_sweep
+            if constexpr (LAZY) lazy = cull_on && lazy_on;
             for (uint32_t n = lg; n < nN; n += G) {
                 float2 s = stE[n];
                 const TgtLds tl = tgt[n];
@@ -611,11 +624,13 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                     box_muller<MATH>(r.x, r.y, z0, z1);
                     u0 = u01(r.z);
                     u1 = u01(r.w);
-                    const u32x4 q = draw_block(p.seed, gid, n, blk, TAG_ANGLE);
-                    a0 = u01(q.x);
-                    a1 = u01(q.y);
-                    a2 = u01(q.z);
-                    a3 = u01(q.w);
+                    if (!lazy) {
+                        const u32x4 q = draw_block(p.seed, gid, n, blk, TAG_ANGLE);
+                        a0 = u01(q.x);
+                        a1 = u01(q.y);
+                        a2 = u01(q.z);
+                        a3 = u01(q.w);
+                    }
                 }
                 const float shift = n < p.nA ? p.b_stored : 0.0f;
                 if (actA) {
@@ -627,9 +642,14 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                         a1 = d[2 * nN + 2 * n + 1];
                     }
                     sab_mh<KIND, RULE, MATH>(tl, s.x, s.y, p.stepsize, z0, u0);
-                    float2 t = transverse<MATH>(MATH == MCMC_MATH_FAST ? s.x * p.pos_scale : s.x, a0, a1);
-                    if (n < p.nA) t.x = shift + t.x;
-                    trAE[n] = t;
+                    const float rs = MATH == MCMC_MATH_FAST ? s.x * p.pos_scale : s.x;
+                    if (lazy) {
+                        trAE[n] = make_float2(rs, 0.0f);
+                    } else {
+                        float2 t = transverse<MATH>(rs, a0, a1);
+                        if (n < p.nA) t.x = shift + t.x;
+                        trAE[n] = t;
+                    }
                 }
                 if (actB) {
                     if constexpr (INJ) {
@@ -640,20 +660,65 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                         a3 = d[2 * nN + 2 * n + 1];
                     }
                     sab_mh<KIND, RULE, MATH>(tl, s.x, s.y, p.stepsize, z1, u1);
-                    float2 t = transverse<MATH>(MATH == MCMC_MATH_FAST ? s.x * p.pos_scale : s.x, a2, a3);
-                    if (n < p.nA) t.x = shift + t.x;
-                    trBE[n] = t;
+                    const float rs = MATH == MCMC_MATH_FAST ? s.x * p.pos_scale : s.x;
+                    if (lazy) {
+                        trBE[n] = make_float2(rs, 0.0f);
+                    } else {
+                        float2 t = transverse<MATH>(rs, a2, a3);
+                        if (n < p.nA) t.x = shift + t.x;
+                        trBE[n] = t;
+                    }
                 }
                 stE[n] = s;
             }
             __syncthreads();
-            if (actA) pair_sweep(trAE);
+            if constexpr (LAZY) {
+                if (lazy) {
+                    const uint32_t nAp = 2u * GA < p.nA ? 2u * GA : p.nA;
+                    const uint32_t nBp = 4u * GB < p.nB ? 4u * GB : p.nB;
+                    // radius -> transverse position of nucleon n, both steps of the pair (IntegrateSAB.cuh:50-61)
+                    auto angles = [&](uint32_t n) __attribute__((always_inline)) {
+                        const u32x4 q = draw_block(p.seed, gid, n, blk, TAG_ANGLE);
+                        const float shift = n < p.nA ? p.b_stored : 0.0f;
+                        if (actA) {
+                            float2 t = transverse<MATH>(trAE[n].x, u01(q.x), u01(q.y));
+                            if (n < p.nA) t.x = shift + t.x;
+                            trAE[n] = t;
+                        }
+                        if (actB) {
+                            float2 t = transverse<MATH>(trBE[n].x, u01(q.z), u01(q.w));
+                            if (n < p.nA) t.x = shift + t.x;
+                            trBE[n] = t;
+                        }
+                    };
+                    for (uint32_t t = lg; t < nAp + nBp; t += 64) angles(t < nAp ? t : p.nA + (t - nAp));
+                    __builtin_amdgcn_wave_barrier();
+                    // probes first; what they leave undecided goes through pair_sweep on complete positions
+                    float dmin = __builtin_inff();
+                    if (actA && sab_pairs_inel<4, G, MATH>(p, trAE, nAp, nBp, la, lb, GA, GB, 0u, dmin)) {
+                        h_inel += 1u;
+                        needA = false;
+                    }
+                    dmin = __builtin_inff();
+                    if (actB && sab_pairs_inel<4, G, MATH>(p, trBE, nAp, nBp, la, lb, GA, GB, 0u, dmin)) {
+                        h_inel += 1u;
+                        needB = false;
+                    }
+                    if (needA || needB) {
+                        lazy_on = false;
+                        for (uint32_t n = lg; n < nN; n += 64)
+                            if (!(n < nAp || (n >= p.nA && n < p.nA + nBp))) angles(n);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            if (needA) pair_sweep(trAE);
             if constexpr (HITS) {
                 __syncthreads();
                 if (actA) count_marks();
                 __syncthreads();
             }
-            if (actB) pair_sweep(trBE);
+            if (needB) pair_sweep(trBE);
             if constexpr (HITS) {
                 __syncthreads();
                 if (actB) count_marks();

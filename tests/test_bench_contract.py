@@ -10,7 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r1_bench_v*.json")), key=lambda f: int(f.split("_v")[-1].split(".")[0]))
+    import re
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r1_bench_v*.json")) if re.search(r"r1_bench_v\d+\.json$", f)]
+    files.sort(key=lambda f: int(re.search(r"_v(\d+)\.json$", f).group(1)))
     assert files, "no bench line under profiles/"
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
