@@ -1,58 +1,124 @@
 #!/usr/bin/env python3
-"""bench.py -- MH proposals/sec of the many-chain Metropolis-Hastings kernel.
+"""bench.py -- MH proposals/sec of the many-chain Metropolis-Hastings path.
 
-One "step" = one launch of the hot path over one batch: `--sweeps` MH sweeps of
-every chain (2^24 chains x 3 independent r^2 Woods-Saxon(2.0, 0.54) coordinates
-per GPU, the 3-D target of BASELINE.json configs[1] at the chain count the
-metric is quoted on), with the streaming sufficient statistics (sum, sum of
-squares, accepts) reduced on the device; for N > 1 followed by ONE RCCL
-all-reduce of the statistics vector (the path's only exchange step).  Chains are
-sharded by global chain id (Philox counter), so results do not depend on N.
+`python bench.py --gpus N --steps K --warmup W [--workload chain|nucleon|stress]`
 
-Prints ONE JSON line (see the driver contract in the task statement) with
-`roofline` (FP32 VALU bound: SURVEY.md 8d) and `cpu_baseline` (the oracle's
-restatement of the reference step logic timed on the host cores).
+One "step" = one launch of the hot path over one batch, followed (N > 1) by ONE
+RCCL all-reduce of the sufficient statistics (the path's only exchange step).
+Work is sharded by GLOBAL chain / event id (Philox counter), `--chains` is PER
+GPU (weak scaling), so results do not depend on N.
+
+  chain    (default; BASELINE.json metric, configs[1] target at the metric's chain count)
+           2^24 chains x 3 independent r^2 Woods-Saxon(2.0, 0.54) coordinates per GPU, `--sweeps`
+           sweeps per launch, streaming sum / sum of squares / accepts reduced on the device.
+  nucleon  (configs[2]) radial chains of every nucleon of Pb-208 (or --nucleus au): 2^22 coordinate
+           chains per GPU, one MCIntegrate_R2 launch (IntegrateR2.cuh:7-61) + device row means.
+  stress   (configs[4]) 2^21 chains per GPU on the 64-D Gaussian Sigma_ij = 0.9^|i-j|, lag-1000 ring in
+           HBM, observable written back every sweep.
+
+N ranks: when WORLD_SIZE is unset and --gpus N > 1 this process starts N ranks ITSELF
+(`python -m torch.distributed.run ... bench.py ...`, before anything here touches the GPU) and
+exits with their code; under an external launcher the world size must equal --gpus or every rank
+refuses.  `n_gpus` in the line is the process group's size.
+
+Prints ONE JSON line (driver contract) with `roofline` (FP32 VALU bound: SURVEY.md 8d) and, at
+N = 1, `cpu_baseline` (the oracle's restatement of the reference step logic on the host cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_PROPOSAL = 24.0      # algorithmic FP32 flop per 1-D r^2 WS proposal
+FLOP_R2_ACCUMULATE = 6.0      # "+6" for the Kahan r^2 accumulation of MCIntegrate_R2
+FLOP_MVN_PROPOSAL = 22.0      # single-coordinate update on the tridiagonal Gaussian
 VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E
+NUCLEI = {"pb": (208, 6.62, 0.546), "au": (197, 6.38, 0.535)}   # literature Woods-Saxon sets
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains", type=int, default=1 << 24, help="chains per GPU")
+    ap.add_argument("--workload", default="chain", choices=["chain", "nucleon", "stress"])
+    ap.add_argument("--chains", type=int, default=None,
+                    help="chains per GPU (default 2^24 chain, 2^22 coordinate chains nucleon, 2^21 stress)")
     ap.add_argument("--coords", type=int, default=3)
-    ap.add_argument("--sweeps", type=int, default=256, help="MH sweeps per step (launch)")
-    ap.add_argument("--step-size", type=float, default=2.48,
-                    help="proposal width (2.48 = max-efficiency width of stepsize/results/r2WS_2.0_0.54.png)")
+    ap.add_argument("--sweeps", type=int, default=None, help="MH sweeps per step (default 256; stress 64)")
+    ap.add_argument("--step-size", type=float, default=None,
+                    help="proposal width (chain: 2.48 = max-efficiency width of stepsize/results/r2WS_2.0_0.54.png; "
+                         "nucleon: 2.2 = main.cu:149; stress: 0.8)")
     ap.add_argument("--rule", default="cross", choices=["recip", "nodiv", "log", "cross"],
                     help="accept rule: cross = p' >= U p cross-multiplied (default), recip = the reference's cached-reciprocal form")
     ap.add_argument("--math", default="fast", choices=["fast", "precise"])
-    ap.add_argument("--lags", type=int, default=0, help="lag products inside the timed kernel")
+    ap.add_argument("--lags", type=int, default=0, help="lag products inside the timed kernel (chain)")
+    ap.add_argument("--nucleus", default="pb", choices=sorted(NUCLEI), help="nucleon workload: Pb-208 or Au-197")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other kernels of the path")
-    return ap.parse_args()
+    ap.add_argument("--no-clock", action="store_true", help="skip the in-run shader clock measurement")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.chains is None:
+        args.chains = {"chain": 1 << 24, "nucleon": 1 << 22, "stress": 1 << 21}[args.workload]
+    if args.sweeps is None:
+        args.sweeps = 64 if args.workload == "stress" else 256
+    if args.step_size is None:
+        args.step_size = {"chain": 2.48, "nucleon": 2.2, "stress": 0.8}[args.workload]
+    return args
 
 
+# ---------------------------------------------------------------------------------------------------
+# N ranks from one command line
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n_ranks, argv, port):
+    """The command that starts `n_ranks` ranks of this file (one per GPU) on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run: starts the ranks as children and returns their exit code.  Nothing in this
+    process has touched the GPU (not even torch is imported yet)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL on this pool
+    env["MCMC_BENCH_LAUNCHED_RANKS"] = str(args.gpus)
+    return subprocess.run(launcher_command(args.gpus, argv, free_port()), env=env).returncode
+
+
+def world_from_env(args):
+    """(world, rank, local_rank) of this process; refuses when the launcher's world size is not --gpus."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: world size {world} (WORLD_SIZE) does not equal --gpus {args.gpus}; "
+                         f"start it as `python bench.py --gpus N` (it launches its own ranks) or with "
+                         f"--nproc-per-node equal to --gpus")
+    return world, rank, local_rank
+
+
+# ---------------------------------------------------------------------------------------------------
 def secondary(dev):
     """Short runs of the other kernels of the path (outside the timed region; rank 0, N = 1 only): reported beside the
     headline, never part of `value`.  tools/bench_xs.py, bench_mvn.py, bench_store.py are the full versions."""
     import numpy as np
+    import torch
     from mcmc_amd import api, lib as L
 
     def timed(fn, reps=3):
@@ -104,33 +170,71 @@ def secondary(dev):
     return out
 
 
-def cpu_baseline(args, seconds):
+def cpu_cores():
+    """Threads for the CPU baseline: the box's CPU share (OMP_NUM_THREADS is set to it there), at most 16."""
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    n = int(share) if share.isdigit() and int(share) > 0 else (os.cpu_count() or 1)
+    return max(1, min(16, n, os.cpu_count() or 1))
+
+
+def cpu_baseline(args, seconds, target=(2.0, 0.54), note=""):
     """The oracle's FP32 restatement of Metropolis.cuh:40-52 (+ the library's Philox draws and the
     same three accumulators), one thread per core share; bounded sample of the same workload."""
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     orc = O.Oracle()
-    cores = min(16, os.cpu_count() or 1)
+    cores = cpu_cores()
     sweeps = args.sweeps
+    coords = args.coords if args.workload == "chain" else 1
     t0 = time.perf_counter()
-    orc.baseline_chains_f32(0, 64, args.coords, O.R2WS, 2.0, 0.54, args.step_size, 314159265, 0, sweeps)
+    orc.baseline_chains_f32(0, 64, coords, O.R2WS, target[0], target[1], args.step_size, 314159265, 0, sweeps)
     probe = time.perf_counter() - t0
     per_chain = probe / 64
     chains_per_thread = max(16, int(seconds / per_chain))
 
     def work(i):
-        return orc.baseline_chains_f32(i * chains_per_thread, chains_per_thread, args.coords, O.R2WS, 2.0, 0.54,
+        return orc.baseline_chains_f32(i * chains_per_thread, chains_per_thread, coords, O.R2WS, target[0], target[1],
                                        args.step_size, 314159265, 0, sweeps)
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
-    proposals = cores * chains_per_thread * args.coords * sweeps
-    return {"value": proposals / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
-            "sample": f"{cores * chains_per_thread} chains x {args.coords} coords x {sweeps} sweeps "
-                      f"(oracle/mcmc_oracle.c orc_baseline_chains_f32, one thread per core, {dt:.1f} s)"}
+    proposals = cores * chains_per_thread * coords * sweeps
+    return {"value": proposals / dt, "unit": "proposals/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
+            "sample": f"{cores * chains_per_thread} chains x {coords} coords x {sweeps} sweeps "
+                      f"(oracle/mcmc_oracle.c orc_baseline_chains_f32, one thread per core, {dt:.1f} s){note}"}
+
+
+def cpu_baseline_mvn(args, seconds):
+    """The oracle's restatement of the stress sweep (orc_mvn_chain, Philox draws) on the host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from mcmc_amd import api
+    orc = O.Oracle()
+    cores = cpu_cores()
+    D = 64
+    qd, qo = api.ar1_precision(D, 0.9)
+    sweeps = 2048
+    t0 = time.perf_counter()
+    orc.mvn_chain(qd, qo, [0.0] * D, args.step_size, sweeps, seed=314159265, chain=0)
+    per_chain = time.perf_counter() - t0
+    chains_per_thread = max(1, int(seconds / per_chain))
+
+    def work(i):
+        for c in range(chains_per_thread):
+            orc.mvn_chain(qd, qo, [0.0] * D, args.step_size, sweeps, seed=314159265, chain=i * chains_per_thread + c)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": cores * chains_per_thread * D * sweeps / dt, "unit": "proposals/s", "cores": cores,
+            "nproc": os.cpu_count(), "kind": "port",
+            "sample": f"{cores * chains_per_thread} chains x {D}-D x {sweeps} sweeps (oracle/mcmc_oracle.c orc_mvn_chain, "
+                      f"one thread per core, {dt:.1f} s; includes per-sweep trace stores)"}
 
 
 def cpu_reference_f64(step_size):
@@ -155,25 +259,143 @@ def cpu_reference_f64(step_size):
                       f"RNG cost excluded), {dt:.2f} s"}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+# ---------------------------------------------------------------------------------------------------
+# The three workloads: each returns an object with step() -> float64 statistics tensor (device),
+# launch() (the kernel launches alone, for the event bracket), and the constants of its bench line.
+class ChainWorkload:
+    kernel = "mcmc::chain_kernel"
+
+    def __init__(self, args, rank, world, dev):
+        from mcmc_amd import api, lib as L
+        self.args, self.api, self.L = args, api, L
+        self.rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "log": L.ACCEPT_LOG, "cross": L.ACCEPT_CROSS}[args.rule]
+        self.math = L.MATH_FAST if args.math == "fast" else L.MATH_PRECISE
+        self.target = api.make_target(L.TARGET_R2WS, 2.0, 0.54)   # PDF(), metropolis.hpp:19-23 / main.cu:14-19
+        self.eng = api.ChainEngine(args.chains, args.coords, self.target, args.step_size, precision=32,
+                                   accept_rule=self.rule, math_mode=self.math, n_lags=args.lags, seed=314159265, x0=1.0,
+                                   chain_offset=rank * args.chains, center=2.3, device=dev)
+        self.proposals_per_launch = args.chains * args.coords * args.sweeps
+        self.flop_per_proposal = FLOP_PER_PROPOSAL
+        self.algorithmic_bytes = 2 * 4 * args.chains * args.coords        # state load + store
+
+    def launch(self):
+        return self.eng.run(self.args.sweeps, window_start=True)
+
+    def config(self, world):
+        a = self.args
+        return {"workload": f"mh_chain r2WoodsSaxon(2.0,0.54) x{a.coords} coords, {a.chains} chains/GPU, "
+                            f"{a.sweeps} sweeps/launch, step {a.step_size}",
+                "chains_per_gpu": a.chains, "coords": a.coords, "sweeps_per_step": a.sweeps, "accept_rule": a.rule,
+                "math": a.math, "lags_in_kernel": a.lags, "rng": "philox4x32-10",
+                "parallelism": f"chains sharded over {world} GPU(s)"}
+
+    def estimates(self, st, world):
+        s = self.eng.summary(stats_host=st.cpu().numpy(), n_chains=world * self.args.chains, n_steps=self.args.sweeps)
+        return {"mean_r": s[0]["mean"], "var_r": s[0]["variance"], "acceptance": s[0]["acceptance"]}
+
+
+class NucleonWorkload:
+    kernel = "mcmc::xs_chain_kernel (MCIntegrate_R2)"
+
+    def __init__(self, args, rank, world, dev):
+        from mcmc_amd import api, lib as L
+        self.args, self.api, self.L = args, api, L
+        A, c, a = NUCLEI[args.nucleus]
+        self.A, self.c, self.a = A, c, a
+        self.T = max(1, args.chains // A)                               # events per GPU
+        rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "cross": L.ACCEPT_CROSS}.get(args.rule)
+        if rule is None or args.math != "fast":
+            raise SystemExit("the nucleon workload runs rules recip / nodiv / cross in fast math")
+        self.xs = api.XsEngine(A, 0, self.T, [(L.TARGET_R2WS, c, a)] * A, stepsize=args.step_size, accept_rule=rule,
+                               math_mode=L.MATH_FAST, seed=314159265, event_offset=rank * self.T, device=dev)
+        self.xs.InitSampleFromPdf()
+        self.xs.WarmupMetropolis(64)
+        self.proposals_per_launch = self.T * A * args.sweeps
+        self.flop_per_proposal = FLOP_PER_PROPOSAL + FLOP_R2_ACCUMULATE
+        self.algorithmic_bytes = 3 * 4 * self.T * A + 4 * self.T * A      # state load + store, result store + its row-mean read
+
+    def launch(self):
+        _, run_mean = self.xs.MCIntegrate_R2(self.args.sweeps)
+        return run_mean          # [A] doubles: mean of r^2 over this rank's events (summed over ranks, / world on the host)
+
+    def config(self, world):
+        a = self.args
+        return {"workload": f"nucleon radial chains {a.nucleus.upper()}-{self.A} r2WoodsSaxon({self.c},{self.a}), "
+                            f"{self.T} events x {self.A} nucleons/GPU, MCIntegrate_R2 {a.sweeps} samples/launch, step {a.step_size}",
+                "events_per_gpu": self.T, "nucleons": self.A, "chains_per_gpu": self.T * self.A, "coords": 1,
+                "sweeps_per_step": a.sweeps, "accept_rule": a.rule, "math": a.math, "rng": "philox4x32-10",
+                "parallelism": f"events sharded over {world} GPU(s)"}
+
+    def estimates(self, st, world):
+        r2 = float(st.cpu().numpy().mean()) / world
+        return {"rms_fm": r2 ** 0.5, "mean_r2_fm2": r2}
+
+
+class StressWorkload:
+    kernel = "mcmc::mvn_kernel"
+
+    def __init__(self, args, rank, world, dev):
+        import torch
+        from mcmc_amd import api, lib as L
+        self.args, self.api, self.L = args, api, L
+        self.D, self.lag = 64, 1000
+        qd, qo = api.ar1_precision(self.D, 0.9)
+        self.eng = api.MvnEngine(args.chains, qd, qo, args.step_size, self.lag, math_mode=L.MATH_FAST, seed=314159265, x0=0.0,
+                                 chain_offset=rank * args.chains, device=dev)
+        self.obs = torch.empty((args.sweeps, args.chains), dtype=torch.float32, device=dev)
+        self.proposals_per_launch = args.chains * self.D * args.sweeps
+        self.flop_per_proposal = FLOP_MVN_PROPOSAL
+        # 12 B per chain-sweep (observable write, ring read, ring write) + state load/store per launch
+        self.algorithmic_bytes = args.chains * (args.sweeps * 12 + 2 * 4 * self.D)
+
+    def launch(self):
+        return self.eng.run(self.args.sweeps, window=(0, 1 << 40), samples_obs=self.obs)
+
+    def config(self, world):
+        a = self.args
+        return {"workload": f"stress {self.D}-D Gaussian Sigma=0.9^|i-j|, {a.chains} chains/GPU, lag-{self.lag} ring in HBM, "
+                            f"observable write-back, {a.sweeps} sweeps/launch, step {a.step_size}",
+                "chains_per_gpu": a.chains, "coords": self.D, "sweeps_per_step": a.sweeps, "lag": self.lag,
+                "accept_rule": "log", "math": "fast", "rng": "philox4x32-10",
+                "parallelism": f"chains sharded over {world} GPU(s)"}
+
+    def estimates(self, st, world):
+        s = st.cpu().numpy()
+        n = world * self.args.chains * self.args.sweeps
+        return {"mean_x0": s[0] / n, "acceptance": s[2] / (n * self.D)}
+
+
+WORKLOADS = {"chain": ChainWorkload, "nucleon": NucleonWorkload, "stress": StressWorkload}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args, argv))
+    world, rank, local_rank = world_from_env(args)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # one rank per GPU; the modulo only matters when more ranks than GPUs are rehearsed on one card
-    local_rank %= max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("MCMC_BENCH_BACKEND", "nccl")   # "nccl" is RCCL; "gloo" for a one-GPU rehearsal
+    n_dev = max(torch.cuda.device_count(), 1)
+    if world > n_dev and backend == "nccl":
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {n_dev} "
+                         f"(MCMC_BENCH_BACKEND=gloo rehearses more ranks than GPUs)")
+    local_rank %= n_dev      # only matters when more ranks than GPUs are rehearsed on one card
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("MCMC_BENCH_BACKEND", "nccl")   # "nccl" is RCCL; "gloo" for a one-GPU rehearsal
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group of {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    n_gpus = dist.get_world_size() if dist is not None else 1
 
     trace_on = os.environ.get("MCMC_BENCH_TRACE") == "1"
 
@@ -183,15 +405,10 @@ def main():
 
     trace("process group up")
     from mcmc_amd import api, dist as D, lib as L
-    rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "log": L.ACCEPT_LOG, "cross": L.ACCEPT_CROSS}[args.rule]
-    math = L.MATH_FAST if args.math == "fast" else L.MATH_PRECISE
-    target = api.make_target(L.TARGET_R2WS, 2.0, 0.54)   # PDF(), metropolis.hpp:19-23 / main.cu:14-19
-    eng = api.ChainEngine(args.chains, args.coords, target, args.step_size, precision=32, accept_rule=rule,
-                          math_mode=math, n_lags=args.lags, seed=314159265, x0=1.0,
-                          chain_offset=rank * args.chains, center=2.3, device=dev)
+    wl = WORKLOADS[args.workload](args, rank, world, dev)
 
     def step():
-        st = eng.run(args.sweeps, window_start=True)
+        st = wl.launch()
         D.allreduce_stats(st)          # the one collective per batch: sufficient statistics only (no-op for N = 1)
         return st
 
@@ -211,7 +428,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         evs[i][0].record()
-        st = eng.run(args.sweeps, window_start=True)
+        st = wl.launch()
         evs[i][1].record()
         D.allreduce_stats(st)
     fence()
@@ -219,67 +436,84 @@ def main():
     trace(f"timed region done: {elapsed:.3f} s")
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps
 
-    proposals_per_step = world * args.chains * args.coords * args.sweeps
-    value = proposals_per_step * args.steps / elapsed
-    summ = eng.summary(stats_host=st.cpu().numpy(), n_chains=world * args.chains, n_steps=args.sweeps)
+    value = n_gpus * wl.proposals_per_launch * args.steps / elapsed
+    estimates = wl.estimates(st, n_gpus)
 
     out = None
     if rank == 0:
-        launch_props = args.chains * args.coords * args.sweeps
-        # HBM bytes per launch from the committed PMC passes of this same workload (tools/gpu_profile.sh;
-        # FETCH_SIZE / WRITE_SIZE in their own runs, FETCH doubled per MI355X_MICROARCH.md), else null
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_chain_kernel_v6.json")))
-            if args.chains == 1 << 24 and args.coords == 3 and args.lags == 0:
-                traffic = pm["derived"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        # VALU issue occupancy: issue cycles of the hot loop's instruction mix (tools/isa_mix.py, costs from
-        # tools/ubench2.hip) over the SIMD cycles one wave-proposal actually took (1024 SIMDs, clock from the PMC run)
-        valu = None
-        try:
-            mix = json.load(open(os.path.join(ROOT, "profiles", "r1_chain_kernel_isa_mix.json")))
-            ghz = pm["derived"]["clock_GHz"]
-            if args.rule == "cross" and args.math == "fast" and args.lags == 0:
-                cyc = 1024 * ghz * 1e9 * 64 * (kernel_ms * 1e-3) / launch_props
-                valu = {"measured_cycles_per_wave_proposal": cyc, "clock_GHz": ghz,
-                        "ideal_issue_cycles": mix["issue_cycles_per_wave_proposal_ideal"],
-                        "isolated_cost_issue_cycles": mix["issue_cycles_per_wave_proposal_isolated_costs"],
-                        "frac_of_ideal_issue": mix["issue_cycles_per_wave_proposal_ideal"] / cyc,
-                        "frac_of_isolated_cost_issue": mix["issue_cycles_per_wave_proposal_isolated_costs"] / cyc,
-                        "valu_insts_per_proposal": mix["valu_insts_per_proposal"]}
-        except (OSError, KeyError, ValueError, NameError):
-            pass
-        achieved = FLOP_PER_PROPOSAL * launch_props / (kernel_ms * 1e-3) / 1e12
+        launch_props = wl.proposals_per_launch
+        achieved = wl.flop_per_proposal * launch_props / (kernel_ms * 1e-3) / 1e12
+        roof = {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None, "kernel": wl.kernel, "kernel_ms": kernel_ms,
+                "flop_per_proposal": wl.flop_per_proposal, "proposals_per_launch": launch_props,
+                "algorithmic_bytes_per_launch": wl.algorithmic_bytes,
+                "hbm": {"achieved_GBps": wl.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
+                        "frac": wl.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+        if args.workload == "chain":
+            # HBM bytes per launch: NOT measured in this run -- the committed PMC passes of this same workload
+            # (tools/gpu_profile.sh; FETCH_SIZE / WRITE_SIZE in their own runs, FETCH doubled per MI355X_MICROARCH.md)
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_chain_kernel_v6.json")))
+                if args.chains == 1 << 24 and args.coords == 3 and args.lags == 0:
+                    roof["traffic"] = pm["derived"]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r1_pmc_chain_kernel_v6.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; not this run)"
+            except (OSError, KeyError, ValueError):
+                pass
+            roof["note"] = ("FP32 VALU-issue-bound (state in registers, no per-step HBM traffic). achieved = 24 algorithmic "
+                            "FP32 flop per proposal (SURVEY 8d) / kernel time; Philox integer work and quarter-rate "
+                            "transcendentals are not counted as flops, so frac understates VALU occupancy: valu_issue sets "
+                            "the issue cycles of the loop's instruction mix against the cycles measured with the shader clock "
+                            "of THIS run (DESIGN.md 4.1; counter calibration: profiles/r2_valu_busy_calibrated.json)")
+        elif args.workload == "nucleon":
+            roof["note"] = ("FP32 VALU-issue-bound like the chain kernel; 24 + 6 (Kahan r^2) algorithmic flop per proposal. "
+                            "kernel_ms brackets xs_chain_kernel + the two row-mean kernels of the launch")
+        else:
+            roof["note"] = ("BASELINE configs[4] calls this the HBM-bound path; measured it is VALU-issue-bound: 64 proposals "
+                            "per 12 B of HBM traffic per chain-sweep. `hbm` gives the algorithmic bytes (12 B per chain-sweep + "
+                            "state load/store) against 8 TB/s; bound and frac are the VALU figures (22 flop per single-"
+                            "coordinate update)")
         out = {
-            "metric": "MH proposals/sec", "value": value, "unit": "proposals/s", "n_gpus": world,
+            "metric": "MH proposals/sec", "value": value, "unit": "proposals/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"mh_chain r2WoodsSaxon(2.0,0.54) x{args.coords} coords, "
-                                   f"{args.chains} chains/GPU, {args.sweeps} sweeps/launch, step {args.step_size}",
-                       "chains_per_gpu": args.chains, "coords": args.coords, "sweeps_per_step": args.sweeps,
-                       "accept_rule": args.rule, "math": args.math, "lags_in_kernel": args.lags,
-                       "rng": "philox4x32-10", "parallelism": f"chains sharded over {world} GPU(s)"},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "mcmc::chain_kernel", "kernel_ms": kernel_ms,
-                         "flop_per_proposal": FLOP_PER_PROPOSAL, "proposals_per_launch": launch_props,
-                         "valu_issue": valu,
-                         "note": "FP32 VALU-issue-bound (state in registers, no per-step HBM traffic). achieved = 24 "
-                                 "algorithmic FP32 flop per proposal (SURVEY 8d) / kernel time; Philox integer work and "
-                                 "quarter-rate transcendentals are not counted as flops, so frac understates VALU "
-                                 "occupancy: valu_issue sets the issue cycles of the loop's instruction mix against the "
-                                 "cycles measured (the '% of VALU peak' of SURVEY 8d; DESIGN.md 4.1). traffic = HBM bytes per launch from the PMC passes under profiles/"},
-            "estimates": {"mean_r": summ[0]["mean"], "var_r": summ[0]["variance"],
-                          "acceptance": summ[0]["acceptance"]},
+            "config": wl.config(n_gpus), "roofline": roof, "estimates": estimates,
+            "collective": (f"1 all_reduce(SUM, float64[{st.numel()}]) per step, backend "
+                           f"{'rccl' if backend == 'nccl' else backend}" if n_gpus > 1 else None),
         }
+
+    # Shader clock this kernel sustains, measured in THIS run: the same kernel body with s_memtime / s_memrealtime
+    # stamps around each block's tile loop (diagnostic instantiation, mcmc_chain_clock_probe), after the timed region.
+    if args.workload == "chain" and not args.no_clock and args.math == "fast" and args.rule in ("cross", "recip"):
+        try:
+            for _ in range(3):
+                wl.launch()
+            ghz = api.chain_clock_probe(wl.eng, args.sweeps)
+        except Exception as e:
+            ghz = None
+            trace(f"clock probe failed: {e}")
+        if out is not None and ghz is not None:
+            valu = {"clock_GHz": ghz, "clock_source": "s_memtime / s_memrealtime stamps in this run (mcmc_chain_clock_probe)"}
+            cyc = 1024 * ghz * 1e9 * 64 * (kernel_ms * 1e-3) / wl.proposals_per_launch
+            valu["measured_cycles_per_wave_proposal"] = cyc
+            mix_file = "r2_chain_kernel_isa_mix.json" if os.path.exists(os.path.join(ROOT, "profiles", "r2_chain_kernel_isa_mix.json")) \
+                else "r1_chain_kernel_isa_mix.json"
+            try:
+                mix = json.load(open(os.path.join(ROOT, "profiles", mix_file)))
+                if args.rule == "cross" and args.lags == 0:
+                    valu.update({"ideal_issue_cycles": mix["issue_cycles_per_wave_proposal_ideal"],
+                                 "frac_of_ideal_issue": mix["issue_cycles_per_wave_proposal_ideal"] / cyc,
+                                 "valu_insts_per_proposal": mix["valu_insts_per_proposal"],
+                                 "isa_mix_source": f"profiles/{mix_file} (static, tools/isa_mix.py)"})
+            except (OSError, KeyError, ValueError):
+                pass
+            out["roofline"]["valu_issue"] = valu
+
     # ESS/sec: tau_int = 1 + 2 sum rho_k from the streaming lag-49 accumulators at the same width, on a chain
     # subset after warm-up (outside the timed region); the same launches give the throughput of the kernel
     # with all 49 lag products carried by every chain.
-    if not args.no_ess:
+    if args.workload == "chain" and not args.no_ess:
         sub = min(args.chains, 1 << 22)
-        e2 = api.ChainEngine(sub, args.coords, target, args.step_size, precision=32, accept_rule=rule, math_mode=math,
+        e2 = api.ChainEngine(sub, args.coords, wl.target, args.step_size, precision=32, accept_rule=wl.rule, math_mode=wl.math,
                              n_lags=L.MAX_LAGS, seed=314159265, x0=1.0, chain_offset=rank * args.chains, center=2.3,
                              device=dev)
         e2.run(512, n_lags=0)
@@ -295,11 +529,17 @@ def main():
             out["ess_per_sec"] = value / tau
             out["tau_int"] = tau
             out["lag49_proposals_per_sec_per_gpu"] = sub * args.coords * 1024 / (ea.elapsed_time(eb) * 1e-3)
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and n_gpus == 1 and args.workload == "chain" and not args.no_secondary:
         out["secondary"] = secondary(dev)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-        out["cpu_reference_f64"] = cpu_reference_f64(args.step_size)
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        if args.workload == "chain":
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+            out["cpu_reference_f64"] = cpu_reference_f64(args.step_size)
+        elif args.workload == "nucleon":
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, target=(wl.c, wl.a),
+                                               note="; the chain step only, without the Kahan r^2 accumulation")
+        else:
+            out["cpu_baseline"] = cpu_baseline_mvn(args, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
     if dist is not None:

@@ -114,8 +114,19 @@ typedef struct {
 /* Bytes of workspace mcmc_chain_run needs for these arguments. */
 size_t mcmc_chain_workspace_bytes(const mcmc_chain_args *a);
 
-/* Launch (asynchronous on `stream`). */
+/* Launch (asynchronous on `stream`).
+ * Lag products: the FP64 instantiation folds its partial lag products into FP64 every <= 128 steps; the FP32
+ * instantiations keep P_k in FP32 for the whole launch (per chain; the sum over chains is FP64), so one launch of n
+ * steps carries a relative rounding error of about sqrt(n) 2^-24 on P_k (5e-6 at n = 10^4).  Windows longer than
+ * ~10^5 steps should be split into several launches (window_start = 0 + `ring`), whose statistics the host adds.
+ * chain_offset + n_chains must be <= 2^40 (global chain ids are 40-bit Philox counters). */
 int mcmc_chain_run(const mcmc_chain_args *a, void *stream);
+
+/* Diagnostic, no counterpart in the reference: launches the stamped twin of the kernel `a` selects (FP32, FAST math,
+ * rule CROSS or RECIP, Philox draws, no write-back; the same body plus one s_memtime / s_memrealtime pair per block)
+ * and returns the shader clock it sustained in GHz (median over blocks).  Advances the chains like mcmc_chain_run.
+ * Synchronous; allocates its own stamp buffer.  bench.py uses it to turn kernel time into SIMD cycles.          */
+int mcmc_chain_clock_probe(const mcmc_chain_args *a, double *clock_ghz, void *stream);
 
 /* Host finalisation of a (summed) statistics vector of ONE coordinate:
  * mean, variance (n-1; statistics.hpp:17-28), acceptance ratio
@@ -276,6 +287,9 @@ float mcmc_Sum(const float *samples, int n);
 float mcmc_Average(const float *samples, int n);
 float mcmc_Variance(const float *samples, float avg, int n);
 float mcmc_AutoCorrelation(const float *samples, float avg, int lag, int n);
+/* Statistics.cuh:45-60 and :90-115 -- the overloads that compute the average themselves */
+float mcmc_Variance_n(const float *samples, int n);
+float mcmc_AutoCorrelation_n(const float *samples, int lag, int n);
 /* statistics.hpp:6-57 (FP64 naive) */
 double mcmc_Average_f64(const double *nums, int n);
 double mcmc_Variance_f64(const double *nums, int n);

@@ -83,6 +83,21 @@ class ChainEngine:
                                self.args.center) for c in range(st.shape[0])]
 
 
+def chain_clock_probe(engine, n_steps, n_lags=None):
+    """`mcmc_chain_clock_probe`: shader clock (GHz) the chain kernel of `engine` sustains over one launch of
+    n_steps sweeps (stamped twin of the kernel; advances the chains)."""
+    a = engine.args
+    a.n_steps, a.window_start, a.step_offset = int(n_steps), 1, engine.steps_done
+    a.samples = a.inj_normals = a.inj_uniforms = a.accept_bits = None
+    if n_lags is not None:
+        a.n_lags = int(n_lags)
+    ghz = C.c_double()
+    L.check(_lib.mcmc_chain_clock_probe(C.byref(a), C.byref(ghz), _stream()))
+    engine.steps_done += int(n_steps)
+    engine.window_steps = int(n_steps)
+    return ghz.value
+
+
 def finalize_stats(stats_row, n_lags, n_chains, n_steps, center):
     row = np.ascontiguousarray(stats_row, dtype=np.float64)
     out = L.ChainSummary()
@@ -287,13 +302,13 @@ def Average(samples):
 
 
 def Variance(samples, avg=None):
-    """Statistics.cuh:28 (population, FP32 Kahan) or statistics.hpp:30 (n-1, FP64)."""
+    """Statistics.cuh:28 (population, FP32 Kahan; :45 when avg is None) or statistics.hpp:30 (n-1, FP64)."""
     if np.asarray(samples).dtype == np.float64:
         x, p = _f64(samples)
         return _lib.mcmc_Variance_f64(p, len(x))
     x, p = _f32(samples)
     if avg is None:
-        avg = _lib.mcmc_Average(p, len(x))
+        return _lib.mcmc_Variance_n(p, len(x))
     return _lib.mcmc_Variance(p, float(avg), len(x))
 
 
@@ -304,7 +319,7 @@ def AutoCorrelation(samples, lag, avg=None):
         return _lib.mcmc_AutoCorrelation_f64(p, len(x), int(lag))
     x, p = _f32(samples)
     if avg is None:
-        avg = _lib.mcmc_Average(p, len(x))
+        return _lib.mcmc_AutoCorrelation_n(p, int(lag), len(x))   # Statistics.cuh:90
     return _lib.mcmc_AutoCorrelation(p, float(avg), int(lag), len(x))
 
 

@@ -67,6 +67,15 @@ extern "C" float mcmc_AutoCorrelation(const float *samples, float avg, int lag, 
     return num / den;
 }
 
+// Statistics.cuh:45-60: Variance(float*, int) averages first, then the form above
+extern "C" float mcmc_Variance_n(const float *samples, int n) { return mcmc_Variance(samples, mcmc_Average(samples, n), n); }
+
+// Statistics.cuh:90-115: AutoCorrelation(float*, int lag, int n) likewise
+extern "C" float mcmc_AutoCorrelation_n(const float *samples, int lag, int n)
+{
+    return mcmc_AutoCorrelation(samples, mcmc_Average(samples, n), lag, n);
+}
+
 // statistics.hpp:6-15
 extern "C" double mcmc_Average_f64(const double *nums, int n)
 {

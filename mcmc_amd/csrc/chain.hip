@@ -1,6 +1,9 @@
 // chain.hip -- host side of the many-chain MH kernel: argument checks, kernel
 // selection, launch; and the host finalisation of the statistics vector with
 // the exact formulas of stepsize/include/statistics.hpp:6-57.
+#include <algorithm>
+#include <vector>
+
 #include "chain_kernel.hpp"
 #include "host_common.hpp"
 
@@ -32,12 +35,17 @@ extern "C" size_t mcmc_chain_workspace_bytes(const mcmc_chain_args *a)
     return (size_t)a->n_coords * chain_grid_x(a->n_chains) * MCMC_STATS_LEN(a->n_lags) * sizeof(double);
 }
 
-extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
+namespace {
+// Argument checks + both launches of mcmc_chain_run.  `workspace` holds the block partials (the caller's buffer); `stamps` != nullptr selects the stamped instantiation.
+int chain_launch(const mcmc_chain_args *a, void *workspace, size_t workspace_bytes, uint64_t *stamps, void *stream)
 {
     if (!a) return set_error(MCMC_EINVAL, "null args");
     if (a->n_chains == 0 || a->n_coords == 0) return set_error(MCMC_EINVAL, "n_chains and n_coords must be > 0");
     if (a->n_coords > 65535) return set_error(MCMC_EINVAL, "n_coords must be <= 65535");
     if (a->n_chains > (1ull << 39)) return set_error(MCMC_EINVAL, "n_chains must be <= 2^39");
+    // the Philox counter carries 40 bits of the global chain id (device_common.hpp draw_block)
+    if (a->chain_offset > (1ull << 40) || a->chain_offset + a->n_chains > (1ull << 40))
+        return set_error(MCMC_EINVAL, "chain_offset + n_chains must be <= 2^40 (global chain ids are 40-bit Philox counters)");
     if (a->n_lags > MCMC_MAX_LAGS) return set_error(MCMC_EINVAL, "n_lags must be <= MCMC_MAX_LAGS (49)");
     if (!a->state || !a->stats) return set_error(MCMC_EINVAL, "state and stats must be device pointers");
     if ((a->inj_normals == nullptr) != (a->inj_uniforms == nullptr))
@@ -45,7 +53,7 @@ extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
     if (a->n_lags > 0 && a->window_start && a->n_steps < a->n_lags)
         return set_error(MCMC_EINVAL, "the first launch of a statistics window needs n_steps >= n_lags");
     const size_t need = mcmc_chain_workspace_bytes(a);
-    if (!a->workspace || a->workspace_bytes < need) return set_error(MCMC_ENOMEM, "workspace smaller than mcmc_chain_workspace_bytes()");
+    if (!workspace || workspace_bytes < need) return set_error(MCMC_ENOMEM, "workspace smaller than mcmc_chain_workspace_bytes()");
     if (a->target.kind < 0 || a->target.kind > 3) return set_error(MCMC_EINVAL, "bad target kind");
 
     ChainParams p;
@@ -62,12 +70,13 @@ extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
     p.center = a->center;
     p.target = a->target;
     p.state = a->state;
-    p.partials = (double *)a->workspace;
+    p.partials = (double *)workspace;
     p.ring = a->ring;
     p.samples = a->samples;
     p.inj_normals = a->inj_normals;
     p.inj_uniforms = a->inj_uniforms;
     p.accept_bits = a->accept_bits;
+    p.stamps = stamps;
 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(chain_grid_x(a->n_chains), a->n_coords);
@@ -81,8 +90,45 @@ extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
     if (rc != MCMC_OK) return rc;
     MCMC_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(chain_finalize_kernel, dim3(MCMC_STATS_LEN(a->n_lags), a->n_coords), dim3(256), 0, s,
-                       (const double *)a->workspace, a->stats, (int)MCMC_STATS_LEN(a->n_lags), (int)grid.x);
+                       (const double *)workspace, a->stats, (int)MCMC_STATS_LEN(a->n_lags), (int)grid.x);
     MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+} // namespace
+
+extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
+{
+    if (!a) return set_error(MCMC_EINVAL, "null args");
+    return chain_launch(a, a->workspace, a->workspace_bytes, nullptr, stream);
+}
+
+// Diagnostic (no reference counterpart): the shader clock the chain kernel sustains.  Launches the STAMPED twin of the
+// kernel these arguments select (same body + one s_memtime / s_memrealtime pair per block around its tile loop), and
+// returns the median over blocks of shader cycles per 100 MHz tick, in GHz (MI355X_MICROARCH.md "DVFS give-back" (6)).
+// Advances the chains like mcmc_chain_run.  Synchronous; allocates its own stamp buffer.
+extern "C" int mcmc_chain_clock_probe(const mcmc_chain_args *a, double *clock_ghz, void *stream)
+{
+    if (!a || !clock_ghz) return set_error(MCMC_EINVAL, "null pointer");
+    if (a->n_chains == 0 || a->n_coords == 0) return set_error(MCMC_EINVAL, "n_chains and n_coords must be > 0");
+    const size_t nblk = (size_t)chain_grid_x(a->n_chains) * a->n_coords;
+    uint64_t *d_stamps = nullptr;
+    MCMC_HIP_CHECK(hipMalloc((void **)&d_stamps, nblk * 2 * sizeof(uint64_t)));
+    int rc = MCMC_OK;
+    hipError_t e = hipMemsetAsync(d_stamps, 0, nblk * 2 * sizeof(uint64_t), (hipStream_t)stream);
+    std::vector<uint64_t> h(nblk * 2);
+    if (e == hipSuccess) rc = chain_launch(a, a->workspace, a->workspace_bytes, d_stamps, stream);
+    if (e == hipSuccess && rc == MCMC_OK)
+        e = hipMemcpyAsync(h.data(), d_stamps, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess && rc == MCMC_OK) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d_stamps);
+    if (rc != MCMC_OK) return rc;
+    if (e != hipSuccess) return set_hip_error(e, __FILE__, __LINE__);
+    std::vector<double> ratio;
+    for (size_t b = 0; b < nblk; ++b)
+        if (h[2 * b + 1] > 0) ratio.push_back((double)h[2 * b] / (double)h[2 * b + 1]);
+    if (ratio.empty()) return set_error(MCMC_EINVAL, "the launch was too short for the 100 MHz counter to tick");
+    std::nth_element(ratio.begin(), ratio.begin() + ratio.size() / 2, ratio.end());
+    *clock_ghz = ratio[ratio.size() / 2] * 0.1;
     return MCMC_OK;
 }
 
@@ -193,6 +239,10 @@ extern "C" int mcmc_launch_draws(uint64_t seed, uint64_t chain_offset, uint64_t 
                                  float *angle_u0, float *angle_u1, float *sab_normals, float *sab_uniforms, void *stream)
 {
     if (n_chains == 0) return set_error(MCMC_EINVAL, "n_chains must be > 0");
+    if (n_chains > (1ull << 38)) return set_error(MCMC_EINVAL, "n_chains must be <= 2^38 per launch");
+    if (chain_offset > (1ull << 40) || chain_offset + n_chains > (1ull << 40))
+        return set_error(MCMC_EINVAL, "chain_offset + n_chains must be <= 2^40 (global chain ids are 40-bit Philox counters)");
+    if (coord >= (1u << 24)) return set_error(MCMC_EINVAL, "coord must be < 2^24");
     const dim3 grid((unsigned)((n_chains + 255) / 256)), block(256);
     if (math_mode == MCMC_MATH_FAST)
         hipLaunchKernelGGL(draws_kernel<MCMC_MATH_FAST>, grid, block, 0, (hipStream_t)stream, seed, chain_offset, n_chains,

@@ -37,6 +37,7 @@ struct ChainParams {
     const void *inj_normals;
     const void *inj_uniforms;
     uint8_t *accept_bits;
+    uint64_t *stamps; // STAMP instantiation only: [n_coords][gridDim.x][2] = shader cycles, 100 MHz ticks of the block's tile loop
 };
 
 __device__ __forceinline__ float wave_sum_f32(float v)
@@ -53,7 +54,9 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 // Real = float : Metropolis.cuh:40-52 arithmetic (rules RECIP / NODIV / LOG / CROSS)
 // Real = double: metropolis.hpp:35-47 arithmetic (rule SHORTCIRCUIT)
 // STORE: sample / accept-flag write-back requested (keeps the address arithmetic out of the hot loop otherwise)
-template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, bool STORE>
+// STAMP: diagnostic instantiation (mcmc_chain_clock_probe) -- the same body with one s_memtime / s_memrealtime pair
+//        around the block's tile loop, written to a buffer of their own; no production launch executes a stamp
+template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, bool STORE, bool STAMP = false>
 __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(const ChainParams p)
 {
     constexpr int NL = NLAG > 0 ? NLAG : 1;
@@ -83,12 +86,22 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
     double S1acc = 0.0, S2acc = 0.0;
     uint64_t wacc_all = 0;
 
+    uint64_t stamp_c = 0, stamp_r = 0;
+    if constexpr (STAMP) {
+        stamp_c = __builtin_amdgcn_s_memtime();
+        stamp_r = __builtin_amdgcn_s_memrealtime();
+    }
+
     for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const uint64_t chain = (uint64_t)tile * CHAIN_BLOCK + tid;
         const bool valid = chain < nc;
-        // Lanes past the end (last tile only) replay the LAST chain, which lives in this same tile: same start,
-        // same draws, same trajectory -- so their per-step stores hit that chain's slots with that chain's
-        // values and need no exec masking; only the statistics leave them out.
+        // A wave that lies wholly past the end (last tile only) has nothing to do.  It must not replay a chain:
+        // waves of a block are not synchronised inside this loop, so it could load that chain's state after the
+        // owning wave has stored the advanced one and write a different trajectory into the owner's slots.
+        if ((uint64_t)tile * CHAIN_BLOCK + (uint64_t)wave * 64 >= nc) continue;
+        // Lanes past the end in the SAME wave as the last chain replay it: same start (one load instruction, ahead
+        // of the wave's own store), same draws, same trajectory -- so their per-step stores hit that chain's slots
+        // with that chain's values and need no exec masking; only the statistics leave them out.
         const uint64_t ch = valid ? chain : nc - 1;
         const uint64_t gid = p.chain_offset + ch;
         Real *state = (Real *)p.state + (uint64_t)coord * nc + ch;
@@ -105,6 +118,13 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
         // lag products and the head/tail sums.
         float H[NL + LAGPAD];
         float P[NL];
+        // FP64 instantiation (metropolis.hpp / statistics.hpp arithmetic): the float lag products are folded into
+        // FP64 at every flush (<= 128 steps), like s1 / s2.  The float kernels keep P in FP32 for the launch
+        // (49 more FP64 accumulators would halve their occupancy): see mcmc_hip.h for the bound this puts on n_steps.
+        constexpr int NPD = (NLAG > 0 && sizeof(Real) == 8) ? NL : 1;
+        double PD[NPD];
+#pragma unroll
+        for (int k = 0; k < NPD; ++k) PD[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < NL; ++k) P[k] = 0.0f;
 #pragma unroll
@@ -186,6 +206,13 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
             S2 += (double)s2;
             s1 = 0.0f;
             s2 = 0.0f;
+            if constexpr (NLAG > 0 && sizeof(Real) == 8) {
+#pragma unroll
+                for (int k = 0; k < NL; ++k) {
+                    PD[k] += (double)P[k];
+                    P[k] = 0.0f;
+                }
+            }
         };
 
         // One group of 8 steps = 4 step pairs from 3 Philox blocks (device_common.hpp, packed draws).
@@ -289,7 +316,9 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
             for (int k = 0; k < NL; ++k) {
                 if (k < (int)p.n_lags) {
                     // FP64 across chains: sums must not depend on how chains fall into waves / GPUs
-                    const double pk = wave_sum(valid ? (double)P[k] : 0.0);
+                    double pk_lane = (double)P[k];
+                    if constexpr (sizeof(Real) == 8) pk_lane += PD[k];
+                    const double pk = wave_sum(valid ? pk_lane : 0.0);
                     const double zk = wave_sum(valid ? (double)H[LAGPAD + k] : 0.0);
                     if (lane == 0) {
                         sred[wave][3 + k] += (double)pk;
@@ -316,6 +345,15 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
         for (int w = 0; w < CHAIN_WAVES; ++w) tot += sred[w][tid];
         p.partials[((uint64_t)coord * gridDim.x + blockIdx.x) * len + tid] = tot;
     }
+    if constexpr (STAMP) {
+        const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c;
+        const uint64_t dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
+        if (tid == 0 && p.stamps != nullptr) {
+            uint64_t *o = p.stamps + ((uint64_t)coord * gridDim.x + blockIdx.x) * 2;
+            o[0] = dc;
+            o[1] = dr;
+        }
+    }
 }
 
 // Fixed-order sum of the block partials: grid = (len, n_coords); thread t adds partials
@@ -335,6 +373,14 @@ static __global__ __launch_bounds__(256) void chain_finalize_kernel(const double
         __syncthreads();
     }
     if (threadIdx.x == 0) stats[(uint64_t)coord * len + i] = sh[0];
+}
+
+// the stamped twin of the FAST-math Philox kernels without write-back (what bench.py times)
+template <int KIND, int RULE, int NLAG>
+void launch_chain_stamped(const ChainParams &p, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((chain_kernel<float, KIND, RULE, MCMC_MATH_FAST, NLAG, false, false, true>), grid, dim3(CHAIN_BLOCK), 0,
+                       s, p);
 }
 
 template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ>

@@ -25,16 +25,28 @@ void pick_lag_inj(const ChainParams &p, dim3 grid, hipStream_t s, bool inj)
     }
 }
 
-template <typename Real, int KIND, int RULE, int MATH>
-void pick_lag(const ChainParams &p, dim3 grid, hipStream_t s)
+// diagnostic: the stamped instantiations (mcmc_chain_clock_probe)
+template <int KIND>
+int pick_stamped(const mcmc_chain_args *a, const ChainParams &p, dim3 grid, hipStream_t s)
 {
-    if (p.n_lags == 0) launch_chain<Real, KIND, RULE, MATH, 0, false>(p, grid, s);
-    else launch_chain<Real, KIND, RULE, MATH, NLAG_MAX, false>(p, grid, s);
+    if (a->precision != 32 || a->math_mode != MCMC_MATH_FAST || a->inj_normals || a->samples || a->accept_bits)
+        return set_error(MCMC_EINVAL, "the clock probe runs the FP32 FAST-math Philox kernel without write-back");
+    if (a->accept_rule == MCMC_ACCEPT_CROSS) {
+        if (p.n_lags == 0) launch_chain_stamped<KIND, MCMC_ACCEPT_CROSS, 0>(p, grid, s);
+        else launch_chain_stamped<KIND, MCMC_ACCEPT_CROSS, NLAG_MAX>(p, grid, s);
+    } else if (a->accept_rule == MCMC_ACCEPT_RECIP) {
+        if (p.n_lags == 0) launch_chain_stamped<KIND, MCMC_ACCEPT_RECIP, 0>(p, grid, s);
+        else launch_chain_stamped<KIND, MCMC_ACCEPT_RECIP, NLAG_MAX>(p, grid, s);
+    } else {
+        return set_error(MCMC_EINVAL, "the clock probe is instantiated for MCMC_ACCEPT_CROSS and MCMC_ACCEPT_RECIP");
+    }
+    return MCMC_OK;
 }
 
 template <int KIND>
 int pick_rule(const mcmc_chain_args *a, const ChainParams &p, dim3 grid, hipStream_t s)
 {
+    if (p.stamps != nullptr) return pick_stamped<KIND>(a, p, grid, s);
     const bool inj = a->inj_normals != nullptr;
     if (a->precision == 64) {
         if (a->accept_rule != MCMC_ACCEPT_SHORTCIRCUIT)
@@ -54,10 +66,7 @@ int pick_rule(const mcmc_chain_args *a, const ChainParams &p, dim3 grid, hipStre
     case MCMC_ACCEPT_RECIP: pick_lag_inj<float, KIND, MCMC_ACCEPT_RECIP, MCMC_MATH_FAST>(p, grid, s, inj); break;
     case MCMC_ACCEPT_NODIV: pick_lag_inj<float, KIND, MCMC_ACCEPT_NODIV, MCMC_MATH_FAST>(p, grid, s, inj); break;
     case MCMC_ACCEPT_CROSS: pick_lag_inj<float, KIND, MCMC_ACCEPT_CROSS, MCMC_MATH_FAST>(p, grid, s, inj); break;
-    case MCMC_ACCEPT_LOG:
-        if (inj) return set_error(MCMC_EINVAL, "injected draws are not implemented for MCMC_ACCEPT_LOG");
-        pick_lag<float, KIND, MCMC_ACCEPT_LOG, MCMC_MATH_FAST>(p, grid, s);
-        break;
+    case MCMC_ACCEPT_LOG: pick_lag_inj<float, KIND, MCMC_ACCEPT_LOG, MCMC_MATH_FAST>(p, grid, s, inj); break;
     default: return set_error(MCMC_EINVAL, "32-bit accept_rule must be RECIP, NODIV, LOG or CROSS");
     }
     return MCMC_OK;

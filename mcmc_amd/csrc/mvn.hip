@@ -42,6 +42,8 @@ extern "C" int mcmc_mvn_run(const mcmc_mvn_args *a, void *stream)
     if (!a) return set_error(MCMC_EINVAL, "null args");
     if (a->n_chains == 0) return set_error(MCMC_EINVAL, "n_chains must be > 0");
     if (a->n_chains > (1ull << 39)) return set_error(MCMC_EINVAL, "n_chains must be <= 2^39");
+    if (a->chain_offset > (1ull << 40) || a->chain_offset + a->n_chains > (1ull << 40))
+        return set_error(MCMC_EINVAL, "chain_offset + n_chains must be <= 2^40 (global chain ids are 40-bit Philox counters)");
     if (a->dim == 0 || a->dim > MVN_MAX_DIM || (a->dim & 7u)) return set_error(MCMC_EINVAL, "dim must be a multiple of 8, <= 64");
     if (a->observable >= a->dim) return set_error(MCMC_EINVAL, "observable must be a coordinate index < dim");
     if (a->lag == 0) return set_error(MCMC_EINVAL, "lag must be >= 1");

@@ -23,7 +23,11 @@ int check_xs(const mcmc_xs_args *a)
     if (a->nNucleonsA + a->nNucleonsB == 0) return set_error(MCMC_EINVAL, "no nucleons");
     if (a->nNucleonsA + a->nNucleonsB > 65535) return set_error(MCMC_EINVAL, "nNucleons must be <= 65535");
     if (a->totalThreads == 0) return set_error(MCMC_EINVAL, "totalThreads must be > 0");
-    if (a->totalThreads > (1ull << 40)) return set_error(MCMC_EINVAL, "totalThreads must be <= 2^40");
+    // grids: ceil(T / 4) blocks at one event per wavefront must fit 2^31 - 1
+    if (a->totalThreads > (1ull << 32)) return set_error(MCMC_EINVAL, "totalThreads must be <= 2^32 per device");
+    // the Philox counter carries 40 bits of the global event id (device_common.hpp draw_block)
+    if (a->event_offset > (1ull << 40) || a->event_offset + a->totalThreads > (1ull << 40))
+        return set_error(MCMC_EINVAL, "event_offset + totalThreads must be <= 2^40 (global event ids are 40-bit Philox counters)");
     if (!a->targets || !a->prevSample) return set_error(MCMC_EINVAL, "targets and prevSample must be device pointers");
     if (a->accept_rule != MCMC_ACCEPT_RECIP && a->accept_rule != MCMC_ACCEPT_NODIV && a->accept_rule != MCMC_ACCEPT_CROSS)
         return set_error(MCMC_EINVAL, "xsection kernels implement MCMC_ACCEPT_RECIP, MCMC_ACCEPT_NODIV and MCMC_ACCEPT_CROSS");
@@ -276,6 +280,7 @@ extern "C" int mcmc_launch_init_sample_array(float *prevSample, float initSample
     if (!prevSample) return set_error(MCMC_EINVAL, "prevSample is null");
     const uint64_t total = (uint64_t)nNucleons * totalThreads;
     if (total == 0) return set_error(MCMC_EINVAL, "empty sample array");
+    if ((total + 255) / 256 > 0x7fffffffull) return set_error(MCMC_EINVAL, "nNucleons * totalThreads must be < 2^39");
     hipLaunchKernelGGL(init_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        prevSample, initSample, total);
     MCMC_HIP_CHECK(hipGetLastError());

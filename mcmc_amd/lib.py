@@ -81,12 +81,13 @@ class Config(C.Structure):
 
 # Every symbol include/mcmc_hip.h declares (tests/test_abi.py checks the header against this list).
 EXPORTS = [
-    "mcmc_chain_workspace_bytes", "mcmc_chain_run", "mcmc_stats_finalize", "mcmc_launch_draws",
+    "mcmc_chain_workspace_bytes", "mcmc_chain_run", "mcmc_chain_clock_probe",
+    "mcmc_stats_finalize", "mcmc_launch_draws",
     "mcmc_mvn_workspace_bytes", "mcmc_mvn_run", "mcmc_mvn_finalize",
     "mcmc_xs_workspace_bytes", "mcmc_launch_init_sample_array", "mcmc_launch_warmup_metropolis",
     "mcmc_launch_init_sample_from_pdf", "mcmc_launch_integrate_r2", "mcmc_launch_integrate_sab", "mcmc_launch_integrate_inel", "mcmc_launch_row_mean_f32",
     "mcmc_row_mean_workspace_bytes",
-    "mcmc_Sum", "mcmc_Average", "mcmc_Variance", "mcmc_AutoCorrelation",
+    "mcmc_Sum", "mcmc_Average", "mcmc_Variance", "mcmc_AutoCorrelation", "mcmc_Variance_n", "mcmc_AutoCorrelation_n",
     "mcmc_Average_f64", "mcmc_Variance_f64", "mcmc_AutoCorrelation_f64", "mcmc_cross_sections",
     "mcmc_config_default", "mcmc_create", "mcmc_destroy", "mcmc_warmup", "mcmc_integrate_r2",
     "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_run_inel_scan", "mcmc_init_from_pdf", "mcmc_get_state", "mcmc_wait",
@@ -104,6 +105,7 @@ def _load():
     lib.mcmc_chain_workspace_bytes.restype = C.c_size_t
     lib.mcmc_chain_workspace_bytes.argtypes = [P(ChainArgs)]
     lib.mcmc_chain_run.argtypes = [P(ChainArgs), C.c_void_p]
+    lib.mcmc_chain_clock_probe.argtypes = [P(ChainArgs), P(C.c_double), C.c_void_p]
     lib.mcmc_stats_finalize.argtypes = [P(C.c_double), C.c_uint32, C.c_uint64, C.c_uint64, C.c_double,
                                         P(ChainSummary), P(C.c_double)]
     lib.mcmc_launch_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
@@ -134,6 +136,10 @@ def _load():
     lib.mcmc_Variance.argtypes = [P(C.c_float), C.c_float, C.c_int]
     lib.mcmc_AutoCorrelation.restype = C.c_float
     lib.mcmc_AutoCorrelation.argtypes = [P(C.c_float), C.c_float, C.c_int, C.c_int]
+    lib.mcmc_Variance_n.restype = C.c_float
+    lib.mcmc_Variance_n.argtypes = [P(C.c_float), C.c_int]
+    lib.mcmc_AutoCorrelation_n.restype = C.c_float
+    lib.mcmc_AutoCorrelation_n.argtypes = [P(C.c_float), C.c_int, C.c_int]
     for f in ("mcmc_Average_f64", "mcmc_Variance_f64"):
         getattr(lib, f).restype = C.c_double
         getattr(lib, f).argtypes = [P(C.c_double), C.c_int]

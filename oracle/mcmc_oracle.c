@@ -384,6 +384,42 @@ ORC_API float orc_autocorrelation_f32(const float *samples, float avg, int lag, 
     return num / den;
 }
 
+/* Statistics.cuh:45-60 -- Variance(float*, int): the average first (:46), then the same Kahan loop. */
+ORC_API float orc_variance_n_f32(const float *samples, int n)
+{
+    float avg = orc_average_f32(samples, n);
+    float res = 0.0f, err = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        float y = samples[i] - avg;
+        y = y * y - err;
+        float t = res + y;
+        err = (t - res) - y;
+        res = t;
+    }
+    return res / n;
+}
+
+/* Statistics.cuh:90-115 -- AutoCorrelation(float*, int lag, int n): the average first (:91). */
+ORC_API float orc_autocorrelation_n_f32(const float *samples, int lag, int n)
+{
+    float avg = orc_average_f32(samples, n);
+    float num = 0.0f, den = 0.0f, err = 0.0f;
+    for (int i = 0; i < n - lag; ++i) {
+        float y = (samples[i] - avg) * (samples[i + lag] - avg) - err;
+        float t = num + y;
+        err = (t - num) - y;
+        num = t;
+    }
+    err = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        float y = (samples[i] - avg) * (samples[i] - avg) - err;
+        float t = den + y;
+        err = (t - den) - y;
+        den = t;
+    }
+    return num / den;
+}
+
 /* ------------------------------------------------------------------ */
 /* a5-a8: one reference GPU "thread" = one event of nN radial coordinates.
  * A thread's draw stream is consumed in the reference order: per sweep, per

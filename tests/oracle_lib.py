@@ -35,6 +35,8 @@ def load_oracle():
     lib.orc_average_f32.restype = C.c_float
     lib.orc_variance_f32.restype = C.c_float
     lib.orc_autocorrelation_f32.restype = C.c_float
+    lib.orc_variance_n_f32.restype = C.c_float
+    lib.orc_autocorrelation_n_f32.restype = C.c_float
     lib.orc_target_f32.restype = C.c_float
     lib.orc_target_f64.restype = C.c_double
     lib.orc_R2WoodsSaxon_f64.restype = C.c_double
@@ -147,6 +149,14 @@ class Oracle:
     def autocorrelation_f32(self, x, avg, lag):
         x = np.ascontiguousarray(x, dtype=np.float32)
         return self.lib.orc_autocorrelation_f32(_ptr(x, C.c_float), C.c_float(avg), C.c_int(lag), C.c_int(len(x)))
+
+    def variance_n_f32(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        return self.lib.orc_variance_n_f32(_ptr(x, C.c_float), C.c_int(len(x)))
+
+    def autocorrelation_n_f32(self, x, lag):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        return self.lib.orc_autocorrelation_n_f32(_ptr(x, C.c_float), C.c_int(lag), C.c_int(len(x)))
 
     # --- a5-a12 -----------------------------------------------------------
     @staticmethod

@@ -52,15 +52,20 @@ def test_fp64_cpu_rule_injected_matches_a1(dev, oracle, target, step):
     assert summ[0]["acceptance"] == pytest.approx(tot_acc / (n_steps * n_chains), abs=1e-12)
 
 
-@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast", "cross_fast"])
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast", "cross_fast", "log_fast"])
 @pytest.mark.parametrize("target", [R2WS_REF, R2GAUSS_1, (O.WS, 2.0, 0.54), (O.GAUSS, 1.5, 0.0)])
 def test_fp32_gpu_rule_injected_matches_a5(dev, oracle, mode, target):
     """a5/a7: Metropolis.cuh:40-52 with injected draws, n_coords coordinates per
-    chain (the Gibbs sweep); accept bits identical, positions to 1e-6."""
+    chain (the Gibbs sweep); accept bits identical, positions to 1e-6.  A chain is left out of the bit-for-bit
+    check only if it comes closer to an accept/reject tie than the arithmetic of the mode can resolve: 2e-6 in
+    PRECISE math (OCML expf vs glibc expf: last ulp), 1e-5 in FAST math (v_exp_f32 / v_rcp_f32 / v_log_f32);
+    at ~3000 proposals per chain that is ~1 % / ~6 % of the chains."""
     from mcmc_amd import lib as L
     rule, math = {"recip_precise": (L.ACCEPT_RECIP, L.MATH_PRECISE), "recip_fast": (L.ACCEPT_RECIP, L.MATH_FAST),
-                  "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "cross_fast": (L.ACCEPT_CROSS, L.MATH_FAST)}[mode]
-    n_steps, n_chains, n_coords, step = 1024, 7, 3, 2.2
+                  "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "cross_fast": (L.ACCEPT_CROSS, L.MATH_FAST),
+                  "log_fast": (L.ACCEPT_LOG, L.MATH_FAST)}[mode]
+    tie = 2e-6 if math == L.MATH_PRECISE else 1e-5
+    n_steps, n_chains, n_coords, step = 1024, 16, 3, 2.2
     rng = np.random.default_rng(99)
     normals = rng.standard_normal((n_steps, n_coords, n_chains)).astype(np.float32)
     uniforms = (1.0 - rng.random((n_steps, n_coords, n_chains))).astype(np.float32)  # (0,1]
@@ -77,12 +82,13 @@ def test_fp32_gpu_rule_injected_matches_a5(dev, oracle, mode, target):
     for c in range(n_chains):
         draws = np.stack([normals[:, :, c], uniforms[:, :, c]], axis=-1)  # [step][coord][2]
         x, ref_b, trace, margin = oracle.warmup_thread_trace(tg, [1.0] * n_coords, step, n_steps, draws)
-        # a run that never comes within 1e-5 of an accept/reject tie cannot flip on last-ulp differences of expf
-        if margin > 1e-5:
+        if margin > tie:
             assert np.array_equal(b[:, :, c], ref_b), f"accept bits differ for chain {c} (margin {margin})"
             np.testing.assert_allclose(s[:, :, c], trace, rtol=1e-6, atol=0)
             strict += 1
-    assert strict >= n_chains - 3, "too many chains passed within 1e-5 of a tie to be checked bit for bit"
+    # PRECISE: at most one chain may be left out; FAST: >= 85 %
+    floor = n_chains - 1 if math == L.MATH_PRECISE else int(np.ceil(0.85 * n_chains))
+    assert strict >= floor, f"only {strict} of {n_chains} chains stayed clear of a tie and were checked bit for bit"
     final = eng.state.cpu().numpy()
     np.testing.assert_allclose(final, s[-1], rtol=0, atol=0)
 
@@ -311,4 +317,53 @@ def test_randomised_configurations_against_oracle_stream(dev, oracle):
                     strict += 1
                     assert np.array_equal(b[:, k, c], rb[:, 0]), (case, c, k)
                     np.testing.assert_allclose(s[:, k, c], trace[:, 0], rtol=tol, atol=tol)
-    assert strict >= 0.6 * total
+    # <= 60 proposals per chain and coordinate: a tie within 1e-4 is met by ~1 % of them
+    assert strict >= 0.85 * total, (strict, total)
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 5, 8])
+def test_ragged_last_tile_with_writeback_over_many_tiles(dev, n_steps):
+    """n_chains = 2^20 + 5: more tiles than blocks (the last tile runs on a late grid-stride iteration) and a last
+    tile of which three waves lie wholly past the end.  Those waves must do nothing (they used to replay the last
+    chain unsynchronised with its owner); the lanes beside the last chain replay it in lock-step.  The sample
+    write-back and states of the last chains equal a small re-run of the same global ids."""
+    from mcmc_amd import lib as L
+    N = (1 << 20) + 5
+    kw = dict(n_coords=2, target=R2WS_REF, step=2.48, precision=32, accept_rule=L.ACCEPT_CROSS, math_mode=L.MATH_FAST,
+              n_lags=0, center=2.3, seed=77)
+    for rep in range(3):     # a drifted wave shows only sometimes: a few independent launches
+        a = _engine(dev, n_chains=N, **kw)
+        a.steps_done = rep * 1000
+        smp = torch.empty((n_steps, 2, N), dtype=torch.float32, device=dev)
+        bits = torch.zeros((n_steps, 2, N), dtype=torch.uint8, device=dev)
+        st = a.run(n_steps, samples=smp, accept_bits=bits).clone()
+        h = _engine(dev, n_chains=70, chain_offset=N - 70, **kw)
+        h.steps_done = rep * 1000
+        smp_h = torch.empty((n_steps, 2, 70), dtype=torch.float32, device=dev)
+        bits_h = torch.zeros((n_steps, 2, 70), dtype=torch.uint8, device=dev)
+        h.run(n_steps, samples=smp_h, accept_bits=bits_h)
+        torch.cuda.synchronize()
+        assert torch.equal(smp[:, :, N - 70:], smp_h)
+        assert torch.equal(bits[:, :, N - 70:], bits_h)
+        assert torch.equal(a.state[:, N - 70:], h.state)
+        assert torch.equal(a.state, smp[-1])
+        # accepted proposals == the accept flags written back (every chain counted once, replay lanes not at all)
+        assert st[:, 2].cpu().tolist() == bits.sum(dim=(0, 2), dtype=torch.float64).cpu().tolist()
+
+
+def test_clock_probe_reports_a_plausible_shader_clock(dev):
+    """mcmc_chain_clock_probe: the stamped twin of the bench kernel; MI355X runs 1.2 - 2.5 GHz under this load, and
+    the stamped launch advances the chains exactly like mcmc_chain_run."""
+    from mcmc_amd import api, lib as L
+    kw = dict(n_coords=3, target=R2WS_REF, step=2.48, precision=32, accept_rule=L.ACCEPT_CROSS, math_mode=L.MATH_FAST,
+              n_lags=0, center=2.3, seed=5)
+    a = _engine(dev, n_chains=1 << 22, **kw)
+    b = _engine(dev, n_chains=1 << 22, **kw)
+    ghz = api.chain_clock_probe(a, 256)
+    sb = b.run(256).clone()
+    torch.cuda.synchronize()
+    assert 1.2 < ghz < 2.6, ghz
+    assert torch.equal(a.state, b.state) and torch.equal(a.stats, sb)
+    with pytest.raises(L.McmcError):
+        api.chain_clock_probe(_engine(dev, n_chains=64, n_coords=1, target=R2WS_REF, step=1.0, precision=64,
+                                      accept_rule=L.ACCEPT_SHORTCIRCUIT, math_mode=L.MATH_PRECISE), 64)

@@ -51,6 +51,30 @@ def test_f32_statistics_match_oracle(oracle):
                 assert L.lib.mcmc_AutoCorrelation(_fp(x), C.c_float(avg), k, n) == oracle.autocorrelation_f32(x, avg, k)
 
 
+def test_f32_statistics_overloads_that_average_themselves(oracle):
+    """mcmc_Variance_n / mcmc_AutoCorrelation_n == Statistics.cuh:45-60 / :90-115 (restated with their own loops
+    in the oracle), bit for bit; and equal to the avg-taking forms fed the Kahan average."""
+    L = _lib()
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 17, 4096, 32768):
+        x = (6.4 + rng.standard_normal(n)).astype(np.float32)
+        v = L.lib.mcmc_Variance_n(_fp(x), n)
+        assert v == oracle.variance_n_f32(x)
+        avg = L.lib.mcmc_Average(_fp(x), n)
+        assert v == L.lib.mcmc_Variance(_fp(x), C.c_float(avg), n)
+        if n > 3:
+            for k in (1, 2, 7):
+                r = L.lib.mcmc_AutoCorrelation_n(_fp(x), k, n)
+                assert r == oracle.autocorrelation_n_f32(x, k)
+                assert r == L.lib.mcmc_AutoCorrelation(_fp(x), C.c_float(avg), k, n)
+    # AR(1) series: the lag-1 value is what it should be
+    y = np.zeros(20000, dtype=np.float32)
+    e = rng.standard_normal(20000).astype(np.float32)
+    for i in range(1, len(y)):
+        y[i] = 0.8 * y[i - 1] + e[i]
+    assert abs(L.lib.mcmc_AutoCorrelation_n(_fp(y), 1, len(y)) - 0.8) < 0.02
+
+
 def test_run_estimator_matches_oracle(oracle):
     """main.cu:253-258: mean of run means, stderr = sqrt(popvar/R), RMS, RMS_stderr."""
     from mcmc_amd import api
