@@ -122,6 +122,16 @@ size_t mcmc_chain_workspace_bytes(const mcmc_chain_args *a);
  * chain_offset + n_chains must be <= 2^40 (global chain ids are 40-bit Philox counters). */
 int mcmc_chain_run(const mcmc_chain_args *a, void *stream);
 
+/* mcmc_chain_run that allocates nothing and needs no workspace -- NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation).  The block partials go to a device array inside the library (MCMC_CHAIN_NOALLOC_MAX_BYTES, held by
+ * every GPU the library runs on until the process ends); a->workspace / workspace_bytes are ignored.  Arguments
+ * whose mcmc_chain_workspace_bytes() exceeds that size are rejected with MCMC_ENOMEM.  Results are identical to
+ * mcmc_chain_run.  All calls on one GPU share the array: calls that overlap on one GPU (different streams or
+ * threads) race; calls on one stream are ordered and safe.                                                    */
+#define MCMC_CHAIN_NOALLOC_MAX_BYTES (8u << 20)
+int mcmc_chain_run_noalloc(const mcmc_chain_args *a, void *stream);
+
 /* Diagnostic, no counterpart in the reference: launches the stamped twin of the kernel `a` selects (FP32, FAST math,
  * rule CROSS or RECIP, Philox draws, no write-back; the same body plus one s_memtime / s_memrealtime pair per block)
  * and returns the shader clock it sustained in GHz (median over blocks).  Advances the chains like mcmc_chain_run.

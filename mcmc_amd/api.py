@@ -58,9 +58,10 @@ class ChainEngine:
         self.window_steps = 0
 
     def run(self, n_steps, window_start=True, samples=None, inj_normals=None, inj_uniforms=None, accept_bits=None,
-            n_lags=None):
+            n_lags=None, noalloc=False):
         """Launch n_steps sweeps (asynchronous on the current torch stream).
-        Returns the device stats tensor [n_coords][stats_len]."""
+        Returns the device stats tensor [n_coords][stats_len].  noalloc: through `mcmc_chain_run_noalloc`
+        (the library's static scratch instead of this engine's workspace)."""
         a = self.args
         a.n_steps = int(n_steps)
         a.window_start = 1 if window_start else 0
@@ -71,7 +72,14 @@ class ChainEngine:
         a.accept_bits = _p(accept_bits)
         if n_lags is not None:
             a.n_lags = int(n_lags)
-        L.check(_lib.mcmc_chain_run(C.byref(a), _stream()))
+        if noalloc:
+            ws, a.workspace, a.workspace_bytes = (a.workspace, a.workspace_bytes), None, 0   # prove it is not used
+            try:
+                L.check(_lib.mcmc_chain_run_noalloc(C.byref(a), _stream()))
+            finally:
+                a.workspace, a.workspace_bytes = ws
+        else:
+            L.check(_lib.mcmc_chain_run(C.byref(a), _stream()))
         self.steps_done += int(n_steps)
         self.window_steps = int(n_steps) if window_start else self.window_steps + int(n_steps)
         return self.stats

@@ -2,6 +2,7 @@
 // selection, launch; and the host finalisation of the statistics vector with
 // the exact formulas of stepsize/include/statistics.hpp:6-57.
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "chain_kernel.hpp"
@@ -36,7 +37,8 @@ extern "C" size_t mcmc_chain_workspace_bytes(const mcmc_chain_args *a)
 }
 
 namespace {
-// Argument checks + both launches of mcmc_chain_run.  `workspace` holds the block partials (the caller's buffer); `stamps` != nullptr selects the stamped instantiation.
+// Argument checks + both launches of mcmc_chain_run.  `workspace` holds the block partials (the caller's buffer, or
+// the library's static scratch for mcmc_chain_run_noalloc); `stamps` != nullptr selects the stamped instantiation.
 int chain_launch(const mcmc_chain_args *a, void *workspace, size_t workspace_bytes, uint64_t *stamps, void *stream)
 {
     if (!a) return set_error(MCMC_EINVAL, "null args");
@@ -100,6 +102,49 @@ extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
 {
     if (!a) return set_error(MCMC_EINVAL, "null args");
     return chain_launch(a, a->workspace, a->workspace_bytes, nullptr, stream);
+}
+
+// ---------------------------------------------------------------------
+// mcmc_chain_run for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
+// hipMalloc): the block partials go to a file-scope device array instead of a caller workspace.  Every GPU the
+// library runs on holds its own copy of the array at its own address; the address is looked up once per device
+// (first call on that device, with it current) and only that pointer is ever handed to kernels.
+namespace {
+constexpr size_t CHAIN_SCRATCH_BYTES = MCMC_CHAIN_NOALLOC_MAX_BYTES;
+static __device__ __align__(256) unsigned char chain_scratch[CHAIN_SCRATCH_BYTES];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+std::mutex scratch_mutex;
+void *scratch_ptr[SCRATCH_MAX_DEVICES]; // per device; nullptr = not looked up yet
+
+int chain_scratch_for_current_device(void **out)
+{
+    int dev = -1;
+    MCMC_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) return set_error(MCMC_EINVAL, "device ordinal beyond the scratch table");
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (scratch_ptr[dev] == nullptr) {
+        void *ptr = nullptr;
+        MCMC_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(chain_scratch)));
+        if (ptr == nullptr) return set_error(MCMC_EINVAL, "hipGetSymbolAddress returned a null scratch address");
+        scratch_ptr[dev] = ptr;
+    }
+    *out = scratch_ptr[dev];
+    return MCMC_OK;
+}
+} // namespace
+
+extern "C" int mcmc_chain_run_noalloc(const mcmc_chain_args *a, void *stream)
+{
+    if (!a) return set_error(MCMC_EINVAL, "null args");
+    const size_t need = mcmc_chain_workspace_bytes(a);
+    if (need > CHAIN_SCRATCH_BYTES)
+        return set_error(MCMC_ENOMEM, "mcmc_chain_run_noalloc: n_coords * blocks * MCMC_STATS_LEN(n_lags) * 8 bytes exceeds "
+                                      "MCMC_CHAIN_NOALLOC_MAX_BYTES; use mcmc_chain_run with a workspace");
+    void *ptr = nullptr;
+    const int rc = chain_scratch_for_current_device(&ptr);
+    if (rc != MCMC_OK) return rc;
+    // every partial the finalisation reads is written by this launch's blocks first: nothing to clear
+    return chain_launch(a, ptr, CHAIN_SCRATCH_BYTES, nullptr, stream);
 }
 
 // Diagnostic (no reference counterpart): the shader clock the chain kernel sustains.  Launches the STAMPED twin of the

@@ -14,6 +14,7 @@ TARGET_WS, TARGET_R2WS, TARGET_GAUSS, TARGET_R2GAUSS = 0, 1, 2, 3
 ACCEPT_RECIP, ACCEPT_SHORTCIRCUIT, ACCEPT_NODIV, ACCEPT_LOG, ACCEPT_CROSS = 0, 1, 2, 3, 4
 MATH_PRECISE, MATH_FAST = 0, 1
 MAX_LAGS = 49
+CHAIN_NOALLOC_MAX_BYTES = 8 << 20   # MCMC_CHAIN_NOALLOC_MAX_BYTES
 
 
 def stats_len(n_lags):
@@ -81,7 +82,7 @@ class Config(C.Structure):
 
 # Every symbol include/mcmc_hip.h declares (tests/test_abi.py checks the header against this list).
 EXPORTS = [
-    "mcmc_chain_workspace_bytes", "mcmc_chain_run", "mcmc_chain_clock_probe",
+    "mcmc_chain_workspace_bytes", "mcmc_chain_run", "mcmc_chain_run_noalloc", "mcmc_chain_clock_probe",
     "mcmc_stats_finalize", "mcmc_launch_draws",
     "mcmc_mvn_workspace_bytes", "mcmc_mvn_run", "mcmc_mvn_finalize",
     "mcmc_xs_workspace_bytes", "mcmc_launch_init_sample_array", "mcmc_launch_warmup_metropolis",
@@ -105,6 +106,7 @@ def _load():
     lib.mcmc_chain_workspace_bytes.restype = C.c_size_t
     lib.mcmc_chain_workspace_bytes.argtypes = [P(ChainArgs)]
     lib.mcmc_chain_run.argtypes = [P(ChainArgs), C.c_void_p]
+    lib.mcmc_chain_run_noalloc.argtypes = [P(ChainArgs), C.c_void_p]
     lib.mcmc_chain_clock_probe.argtypes = [P(ChainArgs), P(C.c_double), C.c_void_p]
     lib.mcmc_stats_finalize.argtypes = [P(C.c_double), C.c_uint32, C.c_uint64, C.c_uint64, C.c_double,
                                         P(ChainSummary), P(C.c_double)]
