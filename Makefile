@@ -9,10 +9,11 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclu
 LIB = mcmc_amd/libmcmc_hip.so
 
 OBJS = $(OBJ)/chain.o $(OBJ)/chain_kind_0.o $(OBJ)/chain_kind_1.o $(OBJ)/chain_kind_2.o $(OBJ)/chain_kind_3.o \
-       $(OBJ)/xsection.o $(OBJ)/mvn.o $(OBJ)/capi.o $(OBJ)/errors.o
+       $(OBJ)/xsection.o $(OBJ)/sab_mode_1.o $(OBJ)/sab_mode_2.o $(OBJ)/sab_mode_3.o $(OBJ)/sab_mode_4.o \
+       $(OBJ)/mvn.o $(OBJ)/capi.o $(OBJ)/errors.o
 HDRS = $(wildcard $(CSRC)/*.hpp) include/mcmc_hip.h
 
-all: $(LIB) drivers oracle
+all: $(LIB) drivers oracle probes
 
 $(OBJ):
 	mkdir -p $(OBJ)
@@ -21,6 +22,10 @@ $(OBJ):
 # and the packing costs extra v_mov (measured 907 -> 967 G proposals/s); the S_AB kernel keeps it
 $(OBJ)/chain_kind_%.o: $(CSRC)/chain_kind.hip $(HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -DMCMC_KIND=$* -c $< -o $@
+
+# one translation unit per mode of the S_AB kernel
+$(OBJ)/sab_mode_%.o: $(CSRC)/sab_mode.hip $(HDRS) | $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DMCMC_SAB_MODE=$* -c $< -o $@
 
 $(OBJ)/mvn.o: $(CSRC)/mvn.hip $(HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -c $< -o $@
@@ -48,7 +53,13 @@ oracle:
 clean:
 	rm -rf build $(LIB) mcmc_amd/host/stepsize mcmc_amd/host/xsection
 	$(MAKE) -C oracle clean
-.PHONY: all drivers oracle clean
+.PHONY: all drivers oracle probes clean
+
+# device probe of include/mcmc_distributions.h (tests/test_distributions_header.py)
+probes: tools/bin/dist_probe
+tools/bin/dist_probe: tools/dist_probe.hip include/mcmc_distributions.h
+	@mkdir -p tools/bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Iinclude -o $@ $<
 
 # VALU issue-rate microbenchmark (calibrates the cycle model of tools/isa_mix.py)
 ubench: tools/bin/ubench tools/bin/ubench2 tools/bin/ubench3

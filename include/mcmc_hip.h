@@ -221,8 +221,10 @@ typedef struct {
     const mcmc_target *targets; /* dev [nNucleonsA+nNucleonsB] per-nucleon density (main.cu:47-51)    */
     float *prevSample;          /* dev [nNucleons][totalThreads]; main.cu:126                         */
     float stepsize;             /* main.cu:149,197,335 (2.2f)                                         */
-    int32_t accept_rule;        /* MCMC_ACCEPT_RECIP, _NODIV or _CROSS (CROSS: warm-up and R2 kernels; the
-                                   S_AB kernel then applies the same decision p' >= U p as NODIV)      */
+    int32_t accept_rule;        /* MCMC_ACCEPT_RECIP, _NODIV, _LOG (FAST math) or _CROSS.  CROSS keeps the density as a
+                                   quotient (two cached values per chain): the warm-up and R2 kernels run it as such;
+                                   the S_AB / inelastic kernels hold ONE cached value per nucleon in LDS and evaluate
+                                   CROSS as NODIV -- the same decision p' >= U p, identical away from exact ties */
     int32_t math_mode;
     int32_t uniform_kind;       /* -1: kinds differ per nucleon (read from `targets` on the device);
                                    otherwise every nucleon has this mcmc_target_kind, which selects a
@@ -327,6 +329,11 @@ typedef struct {
     int32_t accept_rule, math_mode;
     int32_t device;            /* HIP device ordinal */
     uint64_t event_offset;     /* global id of this device's event 0 (multi-GPU partition) */
+    int32_t integrateRMS;      /* main.cu:81 (true): mcmc_run_all runs the RMS integration             */
+    int32_t integrateSAB;      /* main.cu:82 (true): mcmc_run_all runs the S_AB scan                   */
+    const char *outDir;        /* main.cu:73 ("../data/"); NULL = "./"                                  */
+    const char *outFile;       /* main.cu:74,77-79 ("out.root"; argv[1]); NULL = "out"; the library appends
+                                  ".RMS.csv" / ".S_AB.csv" (TTree columns of IntegrationOutputHandler.cuh:83-112) */
 } mcmc_config;
 
 typedef struct mcmc_handle_s *mcmc_handle;
@@ -353,6 +360,10 @@ int mcmc_run_sab_scan(mcmc_handle h, float *b, float *S_AB, float *S_AB_stderr, 
  * error (the estimator of main.cu:384-386 applied to the per-run probabilities; 0
  * when totalRuns == 1).                                                          */
 int mcmc_run_inel_scan(mcmc_handle h, float *b, double *p_inel, double *p_inel_stderr, float dmax2);
+/* The body of main() after the warm-up (main.cu:157-416) as the config describes it: the RMS integration when
+ * cfg.integrateRMS, the S_AB scan when cfg.integrateSAB, each written to <outDir><outFile>.RMS.csv / .S_AB.csv with
+ * the reference's TTree column names.  sigma6 (may be NULL) receives mcmc_cross_sections of the scan.           */
+int mcmc_run_all(mcmc_handle h, double *sigma6);
 /* Copy the chain state (prevSample, [nNucleons][totalThreads]) to the host. */
 int mcmc_get_state(mcmc_handle h, float *host_out);
 int mcmc_wait(mcmc_handle h);
@@ -379,6 +390,13 @@ int mcmc_tune_stepsize(const mcmc_target *target, double lo, double hi, int n_wi
 /* Isotope name ("PB-208", "208-pb") -> Z and A: NuclearZAndA, xsection/tools/MCMCMacro.py:63-83
  * (used by IntegrationSettings.SetIsotopeA/B, :145-157: protons = Z, neutrons = A - Z). */
 int mcmc_isotope(const char *name, int *Z, int *A);
+
+/* Diagnostic switches of the S_AB kernels, no counterpart in the reference (INTEGRATION.md "Environment switches"):
+ * "MCMC_SAB_CULL" ("0" = exact pair culling off), "MCMC_SAB_SMALL" ("0" / "1" = general / register kernel for nuclei of
+ * at most 4 + 4 nucleons), "MCMC_SAB_PLAN" ("G,ga_log2").  The environment variables of the same names are read once,
+ * at the first S_AB launch; this call overrides them for the process (value NULL = default).  Results do not depend
+ * on them beyond the order of float multiplications.                                                            */
+int mcmc_set_option(const char *name, const char *value);
 
 const char *mcmc_last_error(void);
 const char *mcmc_version(void);

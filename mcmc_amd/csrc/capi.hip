@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "../host/output.hpp"
 #include "host_common.hpp"
 
 #pragma clang fp contract(off)
@@ -203,6 +204,8 @@ struct mcmc_handle_s {
     size_t scan_len;
     uint64_t sweeps_done;
     int uniform_kind;
+    char outDir[512];  // copies of cfg.outDir / cfg.outFile (the caller's strings need not outlive mcmc_create)
+    char outFile[256];
 };
 
 extern "C" void mcmc_config_default(mcmc_config *c)
@@ -229,6 +232,10 @@ extern "C" void mcmc_config_default(mcmc_config *c)
     c->math_mode = MCMC_MATH_FAST;
     c->device = 0;
     c->event_offset = 0;
+    c->integrateRMS = 1;            // main.cu:81
+    c->integrateSAB = 1;            // main.cu:82
+    c->outDir = nullptr;            // main.cu:73 is "../data/"; the library default is the working directory
+    c->outFile = nullptr;           // main.cu:74 "out.root" -> "out" (+ ".RMS.csv" / ".S_AB.csv")
 }
 
 namespace {
@@ -299,6 +306,10 @@ extern "C" int mcmc_create(const mcmc_config *cfg, mcmc_handle *out)
     h->nN = h->nA + h->nB;
     h->T = (uint64_t)cfg->totalBlocks * (uint64_t)cfg->threadsPerBlock; // main.cu:89
     if (h->nN == 0) { delete h; return set_error(MCMC_EINVAL, "no nucleons"); }
+    std::snprintf(h->outDir, sizeof h->outDir, "%s", cfg->outDir ? cfg->outDir : "./");
+    std::snprintf(h->outFile, sizeof h->outFile, "%s", cfg->outFile ? cfg->outFile : "out");
+    h->cfg.outDir = h->outDir;
+    h->cfg.outFile = h->outFile;
 
     // per-nucleon densities in the order of TemplateBuilder::ConcatArray(pdfArrA, pdfArrB)
     // (main.cu:49-51; MCMCMacro.py:315-345 concatenates protons A, neutrons A, protons B, neutrons B)
@@ -526,6 +537,36 @@ extern "C" int mcmc_run_inel_scan(mcmc_handle h, float *b_out, double *p_inel, d
     return MCMC_OK;
 }
 
+// main.cu:157-416 as the config describes it: RMS integration (:157-286) when integrateRMS, the S_AB scan (:289-413)
+// when integrateSAB, results written with the TTree column names of IntegrationOutputHandler.cuh:83-112 as CSV.
+extern "C" int mcmc_run_all(mcmc_handle h, double *sigma6)
+{
+    if (!h) return set_error(MCMC_EINVAL, "null handle");
+    std::string dir = h->outDir;
+    if (!dir.empty() && dir.back() != '/') dir += '/';
+    const std::string base = dir + h->outFile;
+    if (h->cfg.integrateRMS) {
+        std::vector<float> rms(h->nN), err(h->nN);
+        const int rc = mcmc_run_rms(h, rms.data(), err.data());
+        if (rc) return rc;
+        if (!mcmc_host::write_rms_csv(rms, err, h->nA, base + ".RMS.csv")) return set_error(MCMC_EINVAL, "cannot write <outDir><outFile>.RMS.csv");
+    }
+    if (h->cfg.integrateSAB) {
+        const int n = h->cfg.ndbs;
+        if (n <= 0) return set_error(MCMC_EINVAL, "ndbs must be > 0");
+        std::vector<float> b(n), S(n), E(n);
+        const int rc = mcmc_run_sab_scan(h, b.data(), S.data(), E.data(), nullptr, 0.0f);
+        if (rc) return rc;
+        if (!mcmc_host::write_sab_csv(b, S, E, nullptr, base + ".S_AB.csv")) return set_error(MCMC_EINVAL, "cannot write <outDir><outFile>.S_AB.csv");
+        if (sigma6 && n >= 2) {
+            std::vector<double> bd(b.begin(), b.end()), Sd(S.begin(), S.end()), Ed(E.begin(), E.end());
+            const int rc2 = mcmc_cross_sections(bd.data(), Sd.data(), Ed.data(), n, sigma6);
+            if (rc2) return rc2;
+        }
+    }
+    return MCMC_OK;
+}
+
 extern "C" int mcmc_get_state(mcmc_handle h, float *host_out)
 {
     if (!h || !host_out) return set_error(MCMC_EINVAL, "null pointer");
@@ -536,10 +577,36 @@ extern "C" int mcmc_get_state(mcmc_handle h, float *host_out)
 }
 
 // ---------------------------------------------------------------------
-// stepsize driver in one call (stepsize/src/main.cpp:17-30 for many chains).
-extern "C" int mcmc_stepsize_run(const mcmc_target *target, int precision, int accept_rule, int math_mode, double step,
-                                 uint64_t n_chains, uint32_t n_coords, uint64_t n_warmup, uint64_t n_steps, uint32_t n_lags,
-                                 uint64_t seed, double x0, mcmc_chain_summary *summary, double *rho, void *samples_host)
+// stepsize driver in one call (stepsize/src/main.cpp:17-30 for many chains).  The device buffers live in a small
+// holder so that the step-size study (mcmc_tune_stepsize) allocates once for all its widths.
+namespace {
+struct StepsizeBuffers {
+    void *d_state = nullptr, *d_ws = nullptr, *d_samples = nullptr;
+    double *d_stats = nullptr;
+    size_t state_bytes = 0, ws_bytes = 0, samples_bytes = 0, stats_bytes = 0;
+    std::vector<char> init;
+    ~StepsizeBuffers()
+    {
+        if (d_state) (void)hipFree(d_state);
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_stats) (void)hipFree(d_stats);
+        if (d_samples) (void)hipFree(d_samples);
+    }
+    static hipError_t grow(void **p, size_t *have, size_t need)
+    {
+        if (*have >= need) return hipSuccess;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        *have = 0;
+        const hipError_t e = hipMalloc(p, need);
+        if (e == hipSuccess) *have = need;
+        return e;
+    }
+};
+
+int stepsize_run(StepsizeBuffers &B, const mcmc_target *target, int precision, int accept_rule, int math_mode, double step,
+                 uint64_t n_chains, uint32_t n_coords, uint64_t n_warmup, uint64_t n_steps, uint32_t n_lags, uint64_t seed,
+                 double x0, mcmc_chain_summary *summary, double *rho, void *samples_host)
 {
     if (!target || !summary) return set_error(MCMC_EINVAL, "null pointer");
     if (n_chains == 0 || n_coords == 0 || n_steps == 0) return set_error(MCMC_EINVAL, "n_chains, n_coords and n_steps must be > 0");
@@ -547,15 +614,11 @@ extern "C" int mcmc_stepsize_run(const mcmc_target *target, int precision, int a
     const size_t esz = precision == 64 ? 8 : 4;
     const size_t nstate = (size_t)n_chains * n_coords;
     const int len = MCMC_STATS_LEN(n_lags);
-    void *d_state = nullptr, *d_ws = nullptr, *d_samples = nullptr;
-    double *d_stats = nullptr;
-    int rc = MCMC_OK;
-    hipError_t e = hipSuccess;
 
     mcmc_chain_args a{};
     a.n_chains = n_chains;
     a.n_coords = n_coords;
-    a.n_lags = 0;
+    a.n_lags = n_lags;
     a.step_size = step;
     a.center = 0.0;
     a.target = *target;
@@ -565,60 +628,58 @@ extern "C" int mcmc_stepsize_run(const mcmc_target *target, int precision, int a
     a.seed = seed;
 
     std::vector<double> hstats((size_t)n_coords * len);
-    {
-        a.n_lags = n_lags;
-        const size_t ws_bytes = mcmc_chain_workspace_bytes(&a);
-        if ((e = hipMalloc(&d_state, nstate * esz)) != hipSuccess) goto hip_fail;
-        if ((e = hipMalloc(&d_ws, ws_bytes)) != hipSuccess) goto hip_fail;
-        if ((e = hipMalloc((void **)&d_stats, sizeof(double) * hstats.size())) != hipSuccess) goto hip_fail;
-        if (samples_host && (e = hipMalloc(&d_samples, (size_t)n_steps * nstate * esz)) != hipSuccess) goto hip_fail;
-        a.workspace = d_ws;
-        a.workspace_bytes = ws_bytes;
+    const size_t ws_bytes = mcmc_chain_workspace_bytes(&a);
+    MCMC_HIP_CHECK(StepsizeBuffers::grow(&B.d_state, &B.state_bytes, nstate * esz));
+    MCMC_HIP_CHECK(StepsizeBuffers::grow(&B.d_ws, &B.ws_bytes, ws_bytes));
+    MCMC_HIP_CHECK(StepsizeBuffers::grow((void **)&B.d_stats, &B.stats_bytes, sizeof(double) * hstats.size()));
+    if (samples_host) MCMC_HIP_CHECK(StepsizeBuffers::grow(&B.d_samples, &B.samples_bytes, (size_t)n_steps * nstate * esz));
+    a.workspace = B.d_ws;
+    a.workspace_bytes = ws_bytes;
+    // x0 (metropolis.hpp:29 `double r = 1`)
+    B.init.resize(nstate * esz);
+    for (size_t i = 0; i < nstate; i++) {
+        if (precision == 64) ((double *)B.init.data())[i] = x0;
+        else ((float *)B.init.data())[i] = (float)x0;
     }
-    {
-        // x0 (metropolis.hpp:29 `double r = 1`)
-        std::vector<char> init(nstate * esz);
-        for (size_t i = 0; i < nstate; i++) {
-            if (precision == 64) ((double *)init.data())[i] = x0;
-            else ((float *)init.data())[i] = (float)x0;
-        }
-        if ((e = hipMemcpy(d_state, init.data(), init.size(), hipMemcpyHostToDevice)) != hipSuccess) goto hip_fail;
-    }
-    a.state = d_state;
-    a.stats = d_stats;
+    MCMC_HIP_CHECK(hipMemcpyAsync(B.d_state, B.init.data(), B.init.size(), hipMemcpyHostToDevice, nullptr));
+    a.state = B.d_state;
+    a.stats = B.d_stats;
+    int rc;
     if (n_warmup > 0) {
         a.n_lags = 0;
         a.n_steps = n_warmup;
         a.step_offset = 0;
         a.window_start = 1;
-        if ((rc = mcmc_chain_run(&a, nullptr)) != MCMC_OK) goto done;
+        if ((rc = mcmc_chain_run(&a, nullptr)) != MCMC_OK) return rc;
     }
     a.n_lags = n_lags;
     a.n_steps = n_steps;
     a.step_offset = n_warmup;
     a.window_start = 1;
-    a.samples = d_samples;
+    a.samples = samples_host ? B.d_samples : nullptr;
     // centre the accumulators on the target's bulk to limit cancellation (statistics are shift-invariant)
     a.center = x0;
-    if ((rc = mcmc_chain_run(&a, nullptr)) != MCMC_OK) goto done;
-    if ((e = hipMemcpy(hstats.data(), d_stats, sizeof(double) * hstats.size(), hipMemcpyDeviceToHost)) != hipSuccess) goto hip_fail;
-    if (samples_host &&
-        (e = hipMemcpy(samples_host, d_samples, (size_t)n_steps * nstate * esz, hipMemcpyDeviceToHost)) != hipSuccess)
-        goto hip_fail;
+    if ((rc = mcmc_chain_run(&a, nullptr)) != MCMC_OK) return rc;
+    MCMC_HIP_CHECK(hipMemcpyAsync(hstats.data(), B.d_stats, sizeof(double) * hstats.size(), hipMemcpyDeviceToHost, nullptr));
+    if (samples_host)
+        MCMC_HIP_CHECK(hipMemcpyAsync(samples_host, B.d_samples, (size_t)n_steps * nstate * esz, hipMemcpyDeviceToHost, nullptr));
+    MCMC_HIP_CHECK(hipStreamSynchronize(nullptr));
     for (uint32_t c = 0; c < n_coords; c++) {
         rc = mcmc_stats_finalize(&hstats[(size_t)c * len], n_lags, n_chains, n_steps, a.center, &summary[c],
                                  rho ? rho + (size_t)c * n_lags : nullptr);
-        if (rc) goto done;
+        if (rc) return rc;
     }
-    goto done;
-hip_fail:
-    rc = set_hip_error(e, __FILE__, __LINE__);
-done:
-    if (d_state) (void)hipFree(d_state);
-    if (d_ws) (void)hipFree(d_ws);
-    if (d_stats) (void)hipFree(d_stats);
-    if (d_samples) (void)hipFree(d_samples);
-    return rc;
+    return MCMC_OK;
+}
+} // namespace
+
+extern "C" int mcmc_stepsize_run(const mcmc_target *target, int precision, int accept_rule, int math_mode, double step,
+                                 uint64_t n_chains, uint32_t n_coords, uint64_t n_warmup, uint64_t n_steps, uint32_t n_lags,
+                                 uint64_t seed, double x0, mcmc_chain_summary *summary, double *rho, void *samples_host)
+{
+    StepsizeBuffers B;
+    return stepsize_run(B, target, precision, accept_rule, math_mode, step, n_chains, n_coords, n_warmup, n_steps, n_lags, seed,
+                        x0, summary, rho, samples_host);
 }
 
 // The step-size study of the stepsize executable (stepsize/src/main.cpp:14-36: acceptance and lag-k
@@ -634,11 +695,12 @@ extern "C" int mcmc_tune_stepsize(const mcmc_target *target, double lo, double h
     if (!(lo > 0.0) || !(hi > lo) || n_widths < 3) return set_error(MCMC_EINVAL, "need 0 < lo < hi and n_widths >= 3");
     if (n_steps <= (uint64_t)MCMC_MAX_LAGS + 1) return set_error(MCMC_EINVAL, "n_steps must exceed MCMC_MAX_LAGS + 1");
     std::vector<double> w(n_widths), acc(n_widths), tau(n_widths);
+    StepsizeBuffers B; // one allocation for all widths
     for (int i = 0; i < n_widths; ++i) {
         w[i] = lo + (hi - lo) * i / (n_widths - 1);
         mcmc_chain_summary s;
-        const int rc = mcmc_stepsize_run(target, 32, MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, w[i], n_chains, 1, n_warmup, n_steps,
-                                         MCMC_MAX_LAGS, seed, x0, &s, nullptr, nullptr);
+        const int rc = stepsize_run(B, target, 32, MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, w[i], n_chains, 1, n_warmup, n_steps,
+                                    MCMC_MAX_LAGS, seed, x0, &s, nullptr, nullptr);
         if (rc) return rc;
         acc[i] = s.acceptance;
         tau[i] = s.tau_int;

@@ -41,7 +41,7 @@ struct XsParams {
     uint32_t *hits;        // SAB: [3][T] per-event counters, or nullptr
 };
 
-__global__ void init_sample_kernel(float *prevSample, float v, uint64_t total)
+static __global__ void init_sample_kernel(float *prevSample, float v, uint64_t total)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) prevSample[i] = v;
@@ -73,7 +73,7 @@ __host__ __device__ inline float init_r_max(const mcmc_target &t)
     return 7.0f * sqrtf(t.p0);
 }
 
-__global__ __launch_bounds__(XS_BLOCK) void init_from_pdf_kernel(const mcmc_target *targets, float *prevSample, uint64_t T,
+static __global__ __launch_bounds__(XS_BLOCK) void init_from_pdf_kernel(const mcmc_target *targets, float *prevSample, uint64_t T,
                                                                  uint64_t seed, uint64_t event_offset)
 {
     static_assert(INIT_BINS == 4 * XS_BLOCK, "four bins per thread");
@@ -745,8 +745,8 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
 // hydrogen / helium isotopes): one event per LANE with every nucleon in registers, as the reference does
 // (IntegrateSAB.cuh:30-78) -- no LDS, no barriers.  Same draws (tags 1 and 2, one Philox block per nucleon
 // and step pair and tag), same MH arithmetic and the same Kahan accumulation as sab_kernel, so the chain
-// states are bit-identical to the general kernel's and the per-event means agree to rounding (the pair
-// product is formed in the reference's i-major order here, per lane group there).
+// states and the per-event means are bit-identical to the general kernel's (the pair product is multiplied in
+// that kernel's lane-grid order, see `product` below).
 // Product only, Philox draws, FAST math, r^2 Woods-Saxon densities; everything else takes sab_kernel.
 template <int NA, int NB, int RULE>
 __global__ __launch_bounds__(XS_BLOCK) void sab_small_kernel(const XsParams p)
@@ -793,23 +793,44 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_small_kernel(const XsParams p)
                     if (n < NA) trB[n].x = p.b_stored + trB[n].x;
                 }
             }
-            auto product = [&](const float2 (&tr)[NN]) __attribute__((always_inline)) {
-                float y = 1.0f;
+            // The pair product in the order of sab_kernel at G = 4 lanes per event (what the general kernel runs for
+            // these nuclei): virtual lane l = (la, lb) of the GA x GB grid multiplies, for each of its B nucleons
+            // j = lb + q GB in turn, the factors of its A nucleons i = la + k GA, and the four lane products combine
+            // as (p0 p1)(p2 p3) (group_prod<4>).  Same factors, same order: the per-event means are bit-identical to
+            // the general kernel's, so the choice of kernel (which depends on how many events a device owns) cannot
+            // show in the results.
+            auto product = [&](auto gl_tag, const float2 (&tr)[NN]) __attribute__((always_inline)) {
+                constexpr int GL = decltype(gl_tag)::value, GA = 1 << GL, GB = 4 >> GL;
+                float pl[4];
 #pragma unroll
-                for (int i = 0; i < NA; ++i)
+                for (int l = 0; l < 4; ++l) {
+                    const int la = l & (GA - 1), lb = l >> GL;
+                    pl[l] = 1.0f;
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) { // IntegrateSAB.cuh:66-78
-                        const float dx = tr[i].x - tr[NA + j].x, dy = tr[i].y - tr[NA + j].y;
-                        const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-                        y *= __builtin_fmaf(-p.G0, __builtin_amdgcn_exp2f(-d2), 1.0f);
+                    for (int j = lb; j < NB; j += GB) {
+                        float prq = 1.0f;
+#pragma unroll
+                        for (int i = la; i < NA; i += GA) { // IntegrateSAB.cuh:66-78
+                            const float dx = tr[i].x - tr[NA + j].x, dy = tr[i].y - tr[NA + j].y;
+                            const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+                            prq *= __builtin_fmaf(-p.G0, __builtin_amdgcn_exp2f(-d2), 1.0f);
+                        }
+                        pl[l] *= prq;
                     }
+                }
+                float y = (pl[0] * pl[1]) * (pl[2] * pl[3]);
                 y -= err; // Kahan, IntegrateSAB.cuh:81-85
                 const float tt = sum + y;
                 err = (tt - sum) - y;
                 sum = tt;
             };
-            if (actA) product(trA);
-            if (actB) product(trB);
+            auto product_gl = [&](const float2 (&tr)[NN]) __attribute__((always_inline)) {
+                if (p.ga_log2 == 0) product(std::integral_constant<int, 0>{}, tr);
+                else if (p.ga_log2 == 1) product(std::integral_constant<int, 1>{}, tr);
+                else product(std::integral_constant<int, 2>{}, tr);
+            };
+            if (actA) product_gl(trA);
+            if (actB) product_gl(trB);
         }
     }
     if (valid) {
@@ -840,7 +861,7 @@ __global__ __launch_bounds__(256) void row_partial_kernel(const T *x, uint64_t c
     if (threadIdx.x == 0) partials[(uint64_t)row * RR_CHUNKS + chunk] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
 }
 
-__global__ void row_final_kernel(const double *partials, double *out, uint32_t rows, double scale, int accumulate)
+static __global__ void row_final_kernel(const double *partials, double *out, uint32_t rows, double scale, int accumulate)
 {
     const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
@@ -850,6 +871,6 @@ __global__ void row_final_kernel(const double *partials, double *out, uint32_t r
     out[row] = accumulate ? out[row] + tot : tot;
 }
 
-__global__ void set_double_kernel(double *dst, double v) { *dst = v; }
+static __global__ void set_double_kernel(double *dst, double v) { *dst = v; }
 
 } // namespace mcmc

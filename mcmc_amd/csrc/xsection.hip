@@ -5,15 +5,59 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 
 #include "host_common.hpp"
 #include "xs_kernel.hpp"
 
 using namespace mcmc;
 
+namespace mcmc {
+// one translation unit per MODE of sab_kernel (sab_mode.hip, -DMCMC_SAB_MODE=1..4)
+int launch_sab_mode_1(const mcmc_xs_args *, const XsParams &, int G, size_t lds, bool all_r2ws, hipStream_t);
+int launch_sab_mode_2(const mcmc_xs_args *, const XsParams &, int G, size_t lds, bool all_r2ws, hipStream_t);
+int launch_sab_mode_3(const mcmc_xs_args *, const XsParams &, int G, size_t lds, bool all_r2ws, hipStream_t);
+int launch_sab_mode_4(const mcmc_xs_args *, const XsParams &, int G, size_t lds, bool all_r2ws, hipStream_t);
+} // namespace mcmc
+
 namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Diagnostic switches: read from the environment ONCE, at the first launch that looks at them;
+// mcmc_set_option overrides them afterwards (tests and tools compare kernel variants inside one process).
+struct SabOptions {
+    int cull = -1;   // MCMC_SAB_CULL:  0 = no pair culling, otherwise on
+    int small = -1;  // MCMC_SAB_SMALL: 0 / 1 force the general / the register kernel, -1 = by applicability
+    int plan_g = 0, plan_gl = 0; // MCMC_SAB_PLAN="G,ga_log2" (0 = cost model)
+};
+std::mutex opt_mutex;
+SabOptions opt_state;
+bool opt_loaded = false;
+
+void parse_option(SabOptions &o, const char *name, const char *v)
+{
+    if (std::strcmp(name, "MCMC_SAB_CULL") == 0) o.cull = v && v[0] == '0' ? 0 : -1;
+    else if (std::strcmp(name, "MCMC_SAB_SMALL") == 0) o.small = v && v[0] == '0' ? 0 : v && v[0] == '1' ? 1 : -1;
+    else if (std::strcmp(name, "MCMC_SAB_PLAN") == 0) {
+        int g = 0, gl = 0;
+        o.plan_g = o.plan_gl = 0;
+        if (v && std::sscanf(v, "%d,%d", &g, &gl) == 2 && (g == 4 || g == 16 || g == 64) && gl >= 0 && (1 << gl) <= g)
+            o.plan_g = g, o.plan_gl = gl;
+    }
+}
+
+SabOptions sab_options()
+{
+    std::lock_guard<std::mutex> lock(opt_mutex);
+    if (!opt_loaded) {
+        for (const char *name : {"MCMC_SAB_CULL", "MCMC_SAB_SMALL", "MCMC_SAB_PLAN"})
+            if (const char *v = std::getenv(name)) parse_option(opt_state, name, v);
+        opt_loaded = true;
+    }
+    return opt_state;
+}
 
 size_t rowmean_bytes(uint32_t rows) { return align_up((size_t)rows * RR_CHUNKS * sizeof(double), 256); }
 
@@ -29,8 +73,9 @@ int check_xs(const mcmc_xs_args *a)
     if (a->event_offset > (1ull << 40) || a->event_offset + a->totalThreads > (1ull << 40))
         return set_error(MCMC_EINVAL, "event_offset + totalThreads must be <= 2^40 (global event ids are 40-bit Philox counters)");
     if (!a->targets || !a->prevSample) return set_error(MCMC_EINVAL, "targets and prevSample must be device pointers");
-    if (a->accept_rule != MCMC_ACCEPT_RECIP && a->accept_rule != MCMC_ACCEPT_NODIV && a->accept_rule != MCMC_ACCEPT_CROSS)
-        return set_error(MCMC_EINVAL, "xsection kernels implement MCMC_ACCEPT_RECIP, MCMC_ACCEPT_NODIV and MCMC_ACCEPT_CROSS");
+    if (a->accept_rule != MCMC_ACCEPT_RECIP && a->accept_rule != MCMC_ACCEPT_NODIV && a->accept_rule != MCMC_ACCEPT_CROSS &&
+        a->accept_rule != MCMC_ACCEPT_LOG)
+        return set_error(MCMC_EINVAL, "xsection kernels implement MCMC_ACCEPT_RECIP, _NODIV, _CROSS and _LOG");
     if (a->math_mode == MCMC_MATH_PRECISE && a->accept_rule != MCMC_ACCEPT_RECIP)
         return set_error(MCMC_EINVAL, "precise math implements MCMC_ACCEPT_RECIP only");
     if (a->math_mode != MCMC_MATH_PRECISE && a->math_mode != MCMC_MATH_FAST) return set_error(MCMC_EINVAL, "bad math_mode");
@@ -75,6 +120,9 @@ int launch_chain_xs(const mcmc_xs_args *a, const XsParams &p, hipStream_t s)
     } else if (a->accept_rule == MCMC_ACCEPT_CROSS) {
         if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, true, R2>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, false, R2>), grid, block, 0, s, p);
+    } else if (a->accept_rule == MCMC_ACCEPT_LOG) {
+        if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_LOG, MCMC_MATH_FAST, true, R2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_LOG, MCMC_MATH_FAST, false, R2>), grid, block, 0, s, p);
     } else {
         if (inj) hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, true, R2>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((xs_chain_kernel<MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, false, R2>), grid, block, 0, s, p);
@@ -111,14 +159,10 @@ size_t sab_lds_bytes(int G, uint32_t nA, uint32_t nB, bool hits)
     return align_up(sizeof(TgtLds) * nN, 16) + 3 * sizeof(float2) * epb * nN + (hits ? sizeof(uint32_t) * epb * nN : 0);
 }
 
-SabPlan sab_plan(uint32_t nA, uint32_t nB, bool hits)
+SabPlan sab_plan(uint32_t nA, uint32_t nB, bool hits, const SabOptions &opt)
 {
-    // tuning hook: MCMC_SAB_PLAN="G,ga_log2" overrides the cost model (tools/bench_xs.py --plan)
-    if (const char *ov = std::getenv("MCMC_SAB_PLAN")) {
-        int g = 0, gl = 0;
-        if (std::sscanf(ov, "%d,%d", &g, &gl) == 2 && (g == 4 || g == 16 || g == 64) && gl >= 0 && (1 << gl) <= g)
-            return SabPlan{g, gl, sab_lds_bytes(g, nA, nB, hits)};
-    }
+    // tuning hook: MCMC_SAB_PLAN="G,ga_log2" overrides the cost model (tools/sab_plan_sweep.py)
+    if (opt.plan_g != 0) return SabPlan{opt.plan_g, opt.plan_gl, sab_lds_bytes(opt.plan_g, nA, nB, hits)};
     const int cand[3] = {4, 16, 64};
     SabPlan best{64, 0, sab_lds_bytes(64, nA, nB, hits)};
     double best_cost = 1e300;
@@ -149,49 +193,13 @@ SabPlan sab_plan(uint32_t nA, uint32_t nB, bool hits)
     return best;
 }
 
-template <int G, int KIND, int MODE>
-int launch_sab_g(const mcmc_xs_args *a, const XsParams &p, size_t lds, hipStream_t s)
+int launch_sab(int mode, const mcmc_xs_args *a, const XsParams &p, const SabPlan &plan, bool all_r2ws, hipStream_t s)
 {
-    constexpr int EPB = XS_BLOCK / G;
-    const dim3 grid((unsigned)((p.T + EPB - 1) / EPB));
-    const dim3 block(XS_BLOCK);
-    const bool inj = a->injected != nullptr;
-#define MCMC_SAB_LAUNCH(RULE, MATH, INJ)                                                                         \
-    do {                                                                                                         \
-        auto k = sab_kernel<G, KIND, RULE, MATH, INJ, MODE>;                                                     \
-        if (lds > 48 * 1024)                                                                                     \
-            MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k, grid, block, lds, s, p);                                                           \
-    } while (0)
-    if (a->math_mode == MCMC_MATH_PRECISE) {
-        if (inj) MCMC_SAB_LAUNCH(MCMC_ACCEPT_RECIP, MCMC_MATH_PRECISE, true);
-        else MCMC_SAB_LAUNCH(MCMC_ACCEPT_RECIP, MCMC_MATH_PRECISE, false);
-    } else if (a->accept_rule == MCMC_ACCEPT_RECIP) {
-        if (inj) MCMC_SAB_LAUNCH(MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, true);
-        else MCMC_SAB_LAUNCH(MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, false);
-    } else {
-        if (inj) MCMC_SAB_LAUNCH(MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, true);
-        else MCMC_SAB_LAUNCH(MCMC_ACCEPT_NODIV, MCMC_MATH_FAST, false);
-    }
-#undef MCMC_SAB_LAUNCH
-    MCMC_HIP_CHECK(hipGetLastError());
-    return MCMC_OK;
-}
-
-template <int G, int MODE>
-int launch_sab_kind(const mcmc_xs_args *a, const XsParams &p, size_t lds, bool all_r2ws, hipStream_t s)
-{
-    if (all_r2ws) return launch_sab_g<G, MCMC_TARGET_R2WS, MODE>(a, p, lds, s);
-    return launch_sab_g<G, -1, MODE>(a, p, lds, s);
-}
-
-template <int MODE>
-int launch_sab_mode(const mcmc_xs_args *a, const XsParams &p, const SabPlan &plan, bool all_r2ws, hipStream_t s)
-{
-    switch (plan.G) {
-    case 4: return launch_sab_kind<4, MODE>(a, p, plan.lds, all_r2ws, s);
-    case 16: return launch_sab_kind<16, MODE>(a, p, plan.lds, all_r2ws, s);
-    default: return launch_sab_kind<64, MODE>(a, p, plan.lds, all_r2ws, s);
+    switch (mode) {
+    case 1: return launch_sab_mode_1(a, p, plan.G, plan.lds, all_r2ws, s);
+    case 2: return launch_sab_mode_2(a, p, plan.G, plan.lds, all_r2ws, s);
+    case 3: return launch_sab_mode_3(a, p, plan.G, plan.lds, all_r2ws, s);
+    default: return launch_sab_mode_4(a, p, plan.G, plan.lds, all_r2ws, s);
     }
 }
 
@@ -200,10 +208,9 @@ int launch_sab_mode(const mcmc_xs_args *a, const XsParams &p, const SabPlan &pla
 // d^2 / (2 beta) * log2(e) >= 25 + log2|G0|; 0.05 on that exponent (3.5 % on Gamma) covers the error of
 // v_exp_f32 / expf and of the coordinate differences by orders of magnitude.  Hits: d^2 < dmax2 is impossible
 // beyond sqrt(dmax2) (0.1 % of margin).  MCMC_SAB_CULL=0 switches the culling off (tests compare the two).
-float sab_cull_distance(const mcmc_xs_args *a, const XsParams &p, bool prod, bool hit)
+float sab_cull_distance(const mcmc_xs_args *a, const XsParams &p, bool prod, bool hit, const SabOptions &opt)
 {
-    const char *ov = std::getenv("MCMC_SAB_CULL");
-    if (ov && ov[0] == '0') return 0.0f;
+    if (opt.cull == 0) return 0.0f;
     double c2 = 0.0;
     if (prod) {
         if (!(std::fabs((double)p.G0) > 0.0) || !std::isfinite((double)p.G0)) return 0.0f;
@@ -253,17 +260,33 @@ int launch_sab_small(const mcmc_xs_args *a, const XsParams &p, hipStream_t s)
 // event (measured, He-4 + He-4: 1.96e10 vs 2.58e10 event samples/s at 2^15 events, 4.6e10 vs 3.8e10 at
 // 2^17, 5.65e10 vs 4.57e10 at 2^21), hence the event-count threshold.
 // MCMC_SAB_SMALL=0 / =1 force the general / the register kernel (tests compare the two)
-bool sab_small_applies(const mcmc_xs_args *a, bool product_only)
+// The two kernels give bit-identical results (the register kernel multiplies in the general kernel's G = 4 order),
+// so a choice that depends on this device's share of the events does not show in them.
+bool sab_small_applies(const mcmc_xs_args *a, bool product_only, const SabPlan &plan, const SabOptions &opt)
 {
     if (!product_only || a->injected || a->math_mode != MCMC_MATH_FAST || a->uniform_kind != MCMC_TARGET_R2WS) return false;
+    if (a->accept_rule != MCMC_ACCEPT_RECIP && a->accept_rule != MCMC_ACCEPT_NODIV && a->accept_rule != MCMC_ACCEPT_CROSS)
+        return false;
     if (a->nNucleonsA < 1 || a->nNucleonsA > 4 || a->nNucleonsB < 1 || a->nNucleonsB > 4) return false;
-    const char *ov = std::getenv("MCMC_SAB_SMALL");
-    if (ov && ov[0] == '0') return false;
-    if (ov && ov[0] == '1') return true;
+    if (plan.G != 4) return false;
+    if (opt.small == 0) return false;
+    if (opt.small == 1) return true;
     return a->totalThreads >= (1ull << 17);
 }
 
 } // namespace
+
+// Diagnostic switches, settable from inside the process (value NULL: back to the default).  No reference counterpart.
+extern "C" int mcmc_set_option(const char *name, const char *value)
+{
+    if (!name) return set_error(MCMC_EINVAL, "null option name");
+    if (std::strcmp(name, "MCMC_SAB_CULL") && std::strcmp(name, "MCMC_SAB_SMALL") && std::strcmp(name, "MCMC_SAB_PLAN"))
+        return set_error(MCMC_EINVAL, "unknown option (MCMC_SAB_CULL, MCMC_SAB_SMALL, MCMC_SAB_PLAN)");
+    (void)sab_options(); // the environment first, so that this call wins
+    std::lock_guard<std::mutex> lock(opt_mutex);
+    parse_option(opt_state, name, value);
+    return MCMC_OK;
+}
 
 extern "C" size_t mcmc_row_mean_workspace_bytes(uint32_t rows, uint64_t) { return rowmean_bytes(rows); }
 
@@ -363,14 +386,13 @@ extern "C" int mcmc_launch_integrate_sab(const mcmc_xs_args *a, float *resultBuf
     // `targets` is a device array, so the caller says whether one kind covers all nucleons.
     const bool all_r2ws = a->uniform_kind == MCMC_TARGET_R2WS;
 
-    const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB, hits != nullptr);
+    const SabOptions opt = sab_options();
+    const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB, hits != nullptr, opt);
     if (plan.lds > 160 * 1024) return set_error(MCMC_EINVAL, "nuclei too large for the LDS-resident S_AB kernel (A+B <= ~1600)");
     p.ga_log2 = (uint32_t)plan.ga_log2;
-    p.cull_d = sab_cull_distance(a, p, resultBuffer != nullptr, hits != nullptr);
-    if (sab_small_applies(a, resultBuffer && !hits)) rc = launch_sab_small(a, p, s);
-    else if (resultBuffer && hits) rc = launch_sab_mode<3>(a, p, plan, all_r2ws, s);
-    else if (resultBuffer) rc = launch_sab_mode<1>(a, p, plan, all_r2ws, s);
-    else rc = launch_sab_mode<2>(a, p, plan, all_r2ws, s);
+    p.cull_d = sab_cull_distance(a, p, resultBuffer != nullptr, hits != nullptr, opt);
+    if (sab_small_applies(a, resultBuffer && !hits, plan, opt)) rc = launch_sab_small(a, p, s);
+    else rc = launch_sab(resultBuffer && hits ? 3 : resultBuffer ? 1 : 2, a, p, plan, all_r2ws, s);
     if (rc) return rc;
     if (runMean) {
         rc = row_reduce<float>(resultBuffer, 1, a->totalThreads, 1.0 / (double)a->totalThreads, runMean, 0, a->workspace,
@@ -410,11 +432,12 @@ extern "C" int mcmc_launch_integrate_inel(const mcmc_xs_args *a, uint32_t sample
     p.hit_d2 = dmax2 * p.pos_scale * p.pos_scale;
     uint32_t *hitbuf = (uint32_t *)((char *)a->workspace + rowmean_bytes(nN < 4 ? 4 : nN));
     p.hits = hitbuf;
-    const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB, false);
+    const SabOptions opt = sab_options();
+    const SabPlan plan = sab_plan(a->nNucleonsA, a->nNucleonsB, false, opt);
     if (plan.lds > 160 * 1024) return set_error(MCMC_EINVAL, "nuclei too large for the LDS-resident S_AB kernel (A+B <= ~1600)");
     p.ga_log2 = (uint32_t)plan.ga_log2;
-    p.cull_d = sab_cull_distance(a, p, false, true);
-    rc = launch_sab_mode<4>(a, p, plan, a->uniform_kind == MCMC_TARGET_R2WS, s);
+    p.cull_d = sab_cull_distance(a, p, false, true, opt);
+    rc = launch_sab(4, a, p, plan, a->uniform_kind == MCMC_TARGET_R2WS, s);
     if (rc) return rc;
     rc = row_reduce<uint32_t>(hitbuf, 1, a->totalThreads, 1.0, hits2, 0, a->workspace, a->workspace_bytes, s);
     if (rc) return rc;

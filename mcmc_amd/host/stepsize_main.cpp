@@ -99,8 +99,8 @@ int main(int argc, char **argv)
         usage();
         return 2;
     }
-    if (o.samples && o.chains != 1) {
-        std::fprintf(stderr, "stepsize: --samples writes the reference's one-chain files and needs --chains 1\n");
+    if (o.samples && (o.chains != 1 || o.coords != 1)) { // the sample buffer below holds `iterations` values
+        std::fprintf(stderr, "stepsize: --samples writes the reference's one-chain files and needs --chains 1 --coords 1\n");
         return 2;
     }
     if (mcmc_device_count() <= 0) {

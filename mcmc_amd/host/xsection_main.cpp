@@ -108,8 +108,9 @@ int main(int argc, char **argv)
         else if (k == "sigmaNN") cfg.sigmaNN = fv;
         else if (k == "beta") cfg.beta = fv;
         else if (k == "device") cfg.device = iv;
-        else if (k == "rule") // acceptance test: the reference's p'(1/p) >= U, or the reciprocal-free forms of p' >= U p
-            cfg.accept_rule = v == "cross" ? MCMC_ACCEPT_CROSS : v == "nodiv" ? MCMC_ACCEPT_NODIV : MCMC_ACCEPT_RECIP;
+        else if (k == "rule") // acceptance test: the reference's p'(1/p) >= U, the reciprocal-free forms of p' >= U p, or log space
+            cfg.accept_rule = v == "cross" ? MCMC_ACCEPT_CROSS : v == "nodiv" ? MCMC_ACCEPT_NODIV
+                              : v == "log" ? MCMC_ACCEPT_LOG : MCMC_ACCEPT_RECIP;
         else if (k == "math") cfg.math_mode = v == "precise" ? MCMC_MATH_PRECISE : MCMC_MATH_FAST;
         else if (k == "outDir") outDir = v;
         else if (k == "outFile") outFile = v;
@@ -124,6 +125,10 @@ int main(int argc, char **argv)
         }
     }
     if (!outDir.empty() && outDir.back() != '/') outDir += '/';
+    cfg.outDir = outDir.c_str();   // main.cu:73-82 as config fields (mcmc_run_all reads them; this driver adds the
+    cfg.outFile = outFile.c_str(); // black-disk / inelastic-only / tuned-width options around the same calls)
+    cfg.integrateRMS = integrateRMS;
+    cfg.integrateSAB = integrateSAB;
     if (mcmc_device_count() <= 0) {
         std::fprintf(stderr, "xsection: no HIP device (%s); this build has no CPU path\n", mcmc_last_error());
         return 3;

@@ -77,6 +77,7 @@ class Config(C.Structure):
         ("sigmaNN", C.c_float), ("beta", C.c_float),
         ("accept_rule", C.c_int32), ("math_mode", C.c_int32), ("device", C.c_int32),
         ("event_offset", C.c_uint64),
+        ("integrateRMS", C.c_int32), ("integrateSAB", C.c_int32), ("outDir", C.c_char_p), ("outFile", C.c_char_p),
     ]
 
 
@@ -91,7 +92,7 @@ EXPORTS = [
     "mcmc_Sum", "mcmc_Average", "mcmc_Variance", "mcmc_AutoCorrelation", "mcmc_Variance_n", "mcmc_AutoCorrelation_n",
     "mcmc_Average_f64", "mcmc_Variance_f64", "mcmc_AutoCorrelation_f64", "mcmc_cross_sections",
     "mcmc_config_default", "mcmc_create", "mcmc_destroy", "mcmc_warmup", "mcmc_integrate_r2",
-    "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_run_inel_scan", "mcmc_init_from_pdf", "mcmc_get_state", "mcmc_wait",
+    "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_run_all", "mcmc_set_option", "mcmc_run_inel_scan", "mcmc_init_from_pdf", "mcmc_get_state", "mcmc_wait",
     "mcmc_stepsize_run", "mcmc_tune_stepsize", "mcmc_isotope", "mcmc_last_error", "mcmc_version", "mcmc_device_count",
 ]
 
@@ -158,6 +159,8 @@ def _load():
                                        C.c_float]
     lib.mcmc_run_rms.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float)]
     lib.mcmc_run_sab_scan.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_double), C.c_float]
+    lib.mcmc_run_all.argtypes = [C.c_void_p, P(C.c_double)]
+    lib.mcmc_set_option.argtypes = [C.c_char_p, C.c_char_p]
     lib.mcmc_init_from_pdf.argtypes = [C.c_void_p]
     lib.mcmc_run_inel_scan.argtypes = [C.c_void_p, P(C.c_float), P(C.c_double), P(C.c_double), C.c_float]
     lib.mcmc_get_state.argtypes = [C.c_void_p, P(C.c_float)]

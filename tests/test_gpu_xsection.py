@@ -18,7 +18,28 @@ WS20 = (O.R2WS, 2.0, 0.54)  # main.cu:14-19
 def _modes():
     from mcmc_amd import lib as L
     return {"recip_precise": (L.ACCEPT_RECIP, L.MATH_PRECISE), "recip_fast": (L.ACCEPT_RECIP, L.MATH_FAST),
-            "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "cross_fast": (L.ACCEPT_CROSS, L.MATH_FAST)}
+            "nodiv_fast": (L.ACCEPT_NODIV, L.MATH_FAST), "cross_fast": (L.ACCEPT_CROSS, L.MATH_FAST),
+            "log_fast": (L.ACCEPT_LOG, L.MATH_FAST)}
+
+
+def _tie(mode):
+    """Closest approach to an accept/reject tie below which a chain is left out of the bit-for-bit check: what the
+    arithmetic of the mode can resolve (OCML expf vs glibc expf: last ulp; hardware exp / rcp / log in FAST math)."""
+    return 2e-6 if mode == "recip_precise" else 1e-5
+
+
+@pytest.fixture
+def option():
+    """mcmc_set_option for the duration of a test (the diagnostic switches of the S_AB kernels)."""
+    from mcmc_amd import lib as L
+    touched = []
+
+    def setopt(name, value):
+        touched.append(name)
+        L.check(L.lib.mcmc_set_option(name.encode(), value.encode() if value is not None else None))
+    yield setopt
+    for name in touched:
+        L.lib.mcmc_set_option(name.encode(), None)
 
 
 def _xs(dev, nA, nB, T, targets, mode="recip_precise", **kw):
@@ -35,7 +56,7 @@ def _draws(rng, T, L):
     return d
 
 
-@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast", "cross_fast"])
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast", "cross_fast", "log_fast"])
 @pytest.mark.parametrize("nN", [1, 3, 8])
 def test_warmup_and_r2_injected(dev, oracle, mode, nN):
     """a8 + a10: final state and per-thread Kahan means of r^2 (IntegrateR2.cuh:33-52)."""
@@ -56,19 +77,20 @@ def test_warmup_and_r2_injected(dev, oracle, mode, nN):
         x1, _, _, m1 = oracle.warmup_thread_trace(targets, [1.0] * nN, step, iters, d1[e])
         _, _, _, m2 = oracle.warmup_thread_trace(targets, x1, step, samples, d2[e])
         x2, out = oracle.integrate_r2_thread(targets, x1, step, samples, d2[e])
-        if min(m1, m2) <= 1e-5:
+        if min(m1, m2) <= _tie(mode):
             continue
         strict += 1
         np.testing.assert_allclose(st1[:, e], x1, rtol=1e-6)
         np.testing.assert_allclose(st2[:, e], x2, rtol=1e-6)
         np.testing.assert_allclose(res[:, e], out, rtol=2e-6)
-    assert strict >= T * 0.8
+    # (40 + 64) sweeps x nN proposals per event: a tie within the margin is met by < 2 % of the events
+    assert strict >= (T - 1 if mode == "recip_precise" else T * 0.9), (strict, T)
     # device run mean (replaces host Average, main.cu:221-223) vs the oracle's FP32 Kahan average
     for n in range(nN):
         assert run_mean[n] == pytest.approx(oracle.average_f32(res[n]), rel=1e-6)
 
 
-@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast"])
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "log_fast"])
 @pytest.mark.parametrize("nA,nB", [(2, 2), (4, 4), (3, 5), (12, 12), (16, 20), (70, 70), (208, 208), (197, 63)])
 @pytest.mark.parametrize("b", [0.0, 1.5, 5.0])   # 5.0: nuclei that only graze -- the pair culling of G = 64 is active
 def test_sab_injected(dev, oracle, mode, nA, nB, b):
@@ -97,14 +119,15 @@ def test_sab_injected(dev, oracle, mode, nA, nB, b):
         _, _, _, margin = oracle.warmup_thread_trace(targets, [1.0] * nN, step, samples, mh)
         x, m, h, _ = oracle.integrate_sab_thread(nA, nB, targets, [1.0] * nN, step, samples, b, d[e], dmax2=dmax2)
         tot += h
-        if margin <= 1e-5:
+        if margin <= _tie(mode):
             all_ok = False
             continue
         strict += 1
         np.testing.assert_allclose(st[:, e], x, rtol=1e-6)
         tol = 2e-5 if mode == "recip_precise" else 2e-4
         assert res[e] == pytest.approx(m, rel=tol, abs=1e-7), (e, res[e], m)
-    assert strict >= T * 0.7
+    # samples x nN proposals per event (<= 2500 for Pb-Pb): <= 5 % of the events meet a tie within the FAST margin
+    assert strict >= (T - 1 if mode == "recip_precise" else np.floor(T * 0.85)), (strict, T)
     assert mean[0] == pytest.approx(res.astype(np.float64).mean(), rel=1e-12)
     assert hits[3] == T * samples
     if all_ok:
@@ -230,7 +253,7 @@ def test_inel_injected(dev, oracle, mode, nA, nB, b):
         _, _, _, margin = oracle.warmup_thread_trace(targets, [1.0] * nN, step, samples, mh)
         _, _, h, _ = oracle.integrate_sab_thread(nA, nB, targets, [1.0] * nN, step, samples, b, d[e], dmax2=dmax2)
         tot += h[1]
-        all_ok = all_ok and margin > 1e-5
+        all_ok = all_ok and margin > _tie(mode)
     if all_ok:
         assert abs(inel[0] - tot) <= 1
     else:
@@ -411,17 +434,18 @@ def test_sab_zero_product_exit_changes_nothing(dev, b):
 
 @pytest.mark.parametrize("mode", ["recip_fast", "nodiv_fast"])
 @pytest.mark.parametrize("nA,nB", [(4, 4), (1, 1), (2, 3), (4, 1), (3, 4)])
-def test_sab_light_nuclei_register_kernel_equals_general_kernel(dev, mode, nA, nB, monkeypatch):
+def test_sab_light_nuclei_register_kernel_equals_general_kernel(dev, mode, nA, nB, option):
     """Light nuclei (<= 4 + 4 nucleons, the reference's default He-4 + He-4) take a kernel with one event per lane and
-    the nucleons in registers.  Same draws and step arithmetic as the general LDS kernel: chain states bit-identical,
-    per-event S_AB means equal to rounding (the product is formed in a different order), for a ragged event count,
-    an odd number of samples and a launch that starts on an odd sweep."""
+    the nucleons in registers.  Same draws, same step arithmetic and the same ORDER of the pair product as the general
+    LDS kernel: chain states and per-event S_AB means bit-identical, for a ragged event count, an odd number of
+    samples and a launch that starts on an odd sweep (so the kernel choice, which depends on a device's share of the
+    events, cannot show in the results)."""
     nN = nA + nB
     T, samples, b = 1000, 9, 1.3
     tg = [WS20 if n % 2 == 0 else (O.R2WS, 1.7, 0.5) for n in range(nN)]
     out = []
     for small in ("1", "0"):
-        monkeypatch.setenv("MCMC_SAB_SMALL", small)
+        option("MCMC_SAB_SMALL", small)
         e = _xs(dev, nA, nB, T, tg, mode, seed=31, event_offset=12345)
         e.WarmupMetropolis(5, stepsize=2.2)
         r1, m1, _ = e.MCIntegrate_S_AB(samples, b)
@@ -431,31 +455,46 @@ def test_sab_light_nuclei_register_kernel_equals_general_kernel(dev, mode, nA, n
         out.append((r1.cpu().numpy(), r2.cpu().numpy().copy(), e.prevSample.cpu().numpy().copy(), m2.item()))
     (a1, a2, sa, ma), (g1, g2, sg, mg) = out
     assert np.array_equal(sa, sg)
-    np.testing.assert_allclose(a1, g1, rtol=3e-6, atol=1e-7)
-    np.testing.assert_allclose(a2, g2, rtol=3e-6, atol=1e-7)
-    assert ma == pytest.approx(mg, rel=1e-6)
+    assert np.array_equal(a1, g1) and np.array_equal(a2, g2)
+    assert ma == mg
     assert 0.0 < a1.mean() < 1.0
 
 
-def test_sab_light_nuclei_default_dispatch_is_result_neutral(dev, monkeypatch):
+def test_sab_light_nuclei_default_dispatch_is_result_neutral(dev, option):
     """Without the override the register kernel is taken from 2^17 events on (below that the general kernel is
-    faster); whichever runs, chain states are identical and the integral agrees to rounding."""
+    faster); whichever runs, chain states and per-event integrals are bit-identical."""
     T = 1 << 17
     out = []
     for small in (None, "0"):
-        if small is None:
-            monkeypatch.delenv("MCMC_SAB_SMALL", raising=False)
-        else:
-            monkeypatch.setenv("MCMC_SAB_SMALL", small)
+        option("MCMC_SAB_SMALL", small)
         e = _xs(dev, 4, 4, T, [WS20] * 8, "recip_fast", seed=5)
         e.WarmupMetropolis(4, stepsize=2.2)
         r, m, _ = e.MCIntegrate_S_AB(8, 2.0)
         torch.cuda.synchronize()
         out.append((r.cpu().numpy().copy(), e.prevSample.cpu().numpy().copy(), m.item()))
     (a, sa, ma), (g, sg, mg) = out
-    assert np.array_equal(sa, sg)
-    np.testing.assert_allclose(a, g, rtol=3e-6, atol=1e-7)
-    assert ma == pytest.approx(mg, rel=1e-6)
+    assert np.array_equal(sa, sg) and np.array_equal(a, g) and ma == mg
+
+
+def test_sab_light_nuclei_rank_count_invariance_across_the_kernel_threshold(dev):
+    """He-4 + He-4 (main.cu:38-41), 2^17 events: one device owning all of them takes the register kernel, two ranks
+    owning 2^16 each (event_offset = first global id) take the general kernel.  Per-event S_AB means, chain states and
+    the summed run statistic are bit-identical: results do not depend on the number of ranks."""
+    T, samples, b = 1 << 17, 6, 1.1
+    one = _xs(dev, 4, 4, T, [WS20] * 8, "recip_fast", seed=2025)
+    one.WarmupMetropolis(8, stepsize=2.2)
+    r, m, _ = one.MCIntegrate_S_AB(samples, b)
+    torch.cuda.synchronize()
+    halves = []
+    for off in (0, T // 2):
+        h = _xs(dev, 4, 4, T // 2, [WS20] * 8, "recip_fast", seed=2025, event_offset=off)
+        h.WarmupMetropolis(8, stepsize=2.2)
+        rh, mh, _ = h.MCIntegrate_S_AB(samples, b)
+        torch.cuda.synchronize()
+        halves.append((rh.clone(), h.prevSample.clone(), mh.item()))
+    assert torch.equal(torch.cat([halves[0][0], halves[1][0]]), r)
+    assert torch.equal(torch.cat([halves[0][1], halves[1][1]], dim=1), one.prevSample)
+    assert 0.5 * (halves[0][2] + halves[1][2]) == pytest.approx(m.item(), rel=1e-14)
 
 
 PB = (O.R2WS, 6.62, 0.546)
@@ -464,7 +503,7 @@ PB = (O.R2WS, 6.62, 0.546)
 @pytest.mark.parametrize("nA,nB,b", [(208, 208, 0.0), (208, 208, 9.0), (208, 208, 13.0), (208, 208, 17.0), (208, 208, 40.0),
                                      (197, 63, 7.0), (63, 197, 11.0), (129, 40, 9.5)])
 @pytest.mark.parametrize("mode", ["recip_fast", "recip_precise"])
-def test_sab_exact_pair_culling_changes_nothing(dev, mode, nA, nB, b, monkeypatch):
+def test_sab_exact_pair_culling_changes_nothing(dev, mode, nA, nB, b, option):
     """One event per wavefront: nucleons outside the other nucleus's bounding box grown by the distance at which
     1 - Gamma rounds to exactly 1.0f (and beyond the black-disk radius) are dropped before the pair tile.  Against the
     same launches with MCMC_SAB_CULL=0: chain states and every hit counter identical, the inelastic-only count
@@ -475,7 +514,7 @@ def test_sab_exact_pair_culling_changes_nothing(dev, mode, nA, nB, b, monkeypatc
     dmax2 = 6.76 / np.pi
     out = []
     for cull in ("1", "0"):
-        monkeypatch.setenv("MCMC_SAB_CULL", cull)
+        option("MCMC_SAB_CULL", cull)
         e = _xs(dev, nA, nB, T, [PB] * nN, mode, seed=77)
         e.InitSampleFromPdf()
         e.WarmupMetropolis(6, stepsize=2.2)
@@ -525,3 +564,90 @@ def test_sab_hit_counters_without_the_product(dev, nA, nB, b):
     assert np.array_equal(h3, h2)
     assert np.array_equal(s3, s2)
     assert h3[3] == T * samples
+
+
+@pytest.mark.parametrize("nucleus,A,c,a,r2", [("Au-197", 197, 6.38, 0.535, 28.377538), ("Pb-208", 208, 6.62, 0.546, 30.413841)])
+def test_heavy_nucleus_r2_known_answer(dev, nucleus, A, c, a, r2):
+    """BASELINE configs[2]: radial chains of every nucleon of Au-197 / Pb-208 (literature Woods-Saxon sets):
+    warm-up + MCIntegrate_R2 with the width the device study finds (mcmc_tune_stepsize; the reference hard-codes 2.2),
+    <r^2> against quadrature within 3 standard errors of the run-to-run scatter."""
+    from mcmc_amd import api, lib as L
+    best, _, _, tau = api.TuneStepSize(api.make_target(L.TARGET_R2WS, c, a), 2.0, 6.0, n_widths=9, n_chains=1 << 14,
+                                       n_warmup=600, n_steps=1200)
+    assert 3.0 < best < 5.0, best
+    T, runs, samples = 1024, 8, 256
+    xs = _xs(dev, A, 0, T, [(O.R2WS, c, a)] * A, "cross_fast", seed=1234)
+    xs.InitSampleFromPdf()
+    xs.WarmupMetropolis(512, stepsize=best)
+    means = []
+    for _ in range(runs):
+        _, run_mean = xs.MCIntegrate_R2(samples)
+        torch.cuda.synchronize()
+        means.append(run_mean.cpu().numpy().mean())     # mean over nucleons of the per-nucleon run means
+    means = np.array(means)
+    est, se = means.mean(), means.std(ddof=1) / np.sqrt(runs)
+    assert abs(est - r2) < 3 * se + 1e-3 * r2 * 0.0 + 3e-3, (nucleus, est, se, r2)
+    assert se < 0.02
+
+
+@pytest.mark.parametrize("kernel", ["warmup_r2", "sab", "inel"])
+def test_log_space_rule_on_the_xsection_kernels(dev, kernel):
+    """north_star subsystem (1), log-space acceptance, on the kernels that replace Metropolis.cuh:47-50: the LOG rule
+    makes the same decisions as p' >= U p, so estimates agree with the NODIV rule on the same Philox draws within
+    the statistical error (and the chains are identical wherever no proposal fell on a tie)."""
+    T = 4096
+    if kernel == "warmup_r2":
+        out = {}
+        for mode in ("log_fast", "nodiv_fast"):
+            xs = _xs(dev, 6, 0, T, [WS20] * 6, mode, seed=8)
+            xs.WarmupMetropolis(200, stepsize=2.2)
+            _, rm = xs.MCIntegrate_R2(256)
+            torch.cuda.synchronize()
+            out[mode] = (rm.cpu().numpy().copy(), xs.prevSample.cpu().numpy().copy())
+        same = (out["log_fast"][1] == out["nodiv_fast"][1]).mean()
+        assert same > 0.97, same                      # 456 proposals per chain: a few chains meet a rounding tie
+        np.testing.assert_allclose(out["log_fast"][0], out["nodiv_fast"][0], rtol=2e-3)
+        assert abs(out["log_fast"][0].mean() - 6.424247) < 0.03
+    else:
+        out = {}
+        for mode in ("log_fast", "nodiv_fast"):
+            xs = _xs(dev, 12, 12, T, [WS20] * 24, mode, seed=9)
+            xs.WarmupMetropolis(100, stepsize=2.2)
+            if kernel == "sab":
+                _, m, h = xs.MCIntegrate_S_AB(32, 2.5, dmax2=4.3 / np.pi)
+                torch.cuda.synchronize()
+                out[mode] = (m.item(), h.cpu().numpy().copy())
+            else:
+                h = xs.MCIntegrate_Inel(32, 4.0, 4.3 / np.pi)
+                torch.cuda.synchronize()
+                out[mode] = (0.0, h.cpu().numpy().copy())
+        if kernel == "sab":
+            assert out["log_fast"][0] == pytest.approx(out["nodiv_fast"][0], rel=0.02)
+        np.testing.assert_allclose(out["log_fast"][1], out["nodiv_fast"][1], rtol=0.02)
+
+
+def test_layer_b_run_all_writes_the_reference_tables(dev, tmp_path):
+    """mcmc_config.outDir / outFile / integrateRMS / integrateSAB (main.cu:73-82) + mcmc_run_all (main.cu:157-416):
+    the two tables with the TTree column names of IntegrationOutputHandler.cuh:83-112."""
+    from mcmc_amd import lib as L
+    cfg = L.Config()
+    L.lib.mcmc_config_default(C.byref(cfg))
+    assert cfg.integrateRMS == 1 and cfg.integrateSAB == 1
+    cfg.totalBlocks, cfg.threadsPerBlock, cfg.samplesPerThread, cfg.totalRuns = 8, 128, 32, 3
+    cfg.ndbs, cfg.db = 6, 1.0
+    outdir = str(tmp_path).encode()
+    cfg.outDir, cfg.outFile = outdir, b"he4"
+    h = C.c_void_p()
+    L.check(L.lib.mcmc_create(C.byref(cfg), C.byref(h)))
+    try:
+        L.check(L.lib.mcmc_warmup(h, 2.2, 128))
+        sig = (C.c_double * 6)()
+        L.check(L.lib.mcmc_run_all(h, sig))
+    finally:
+        L.check(L.lib.mcmc_destroy(h))
+    rms = (tmp_path / "he4.RMS.csv").read_text().splitlines()
+    sab = (tmp_path / "he4.S_AB.csv").read_text().splitlines()
+    assert rms[0] == "Nucleus,Nucleon,RMS,RMS_stderr" and len(rms) == 1 + 8
+    assert rms[1].startswith("1,1,") and rms[5].startswith("2,1,")
+    assert sab[0] == "b,S_AB,S_AB_stderr" and len(sab) == 1 + 6
+    assert sig[4] > 0 and sig[0] > sig[4]            # sigma_rxn > 0, sigma_tot > sigma_rxn

@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--bs", default="0,7,14", help="impact parameters (fm) of the Pb-Pb S_AB launches")
     ap.add_argument("--inel-bs", default="0,7,14,18", help="impact parameters (fm) of the Pb-Pb inelastic-only launches")
     args = ap.parse_args()
-    rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "cross": L.ACCEPT_CROSS}[args.rule]
+    rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "cross": L.ACCEPT_CROSS, "log": L.ACCEPT_LOG}[args.rule]
     dev = torch.device("cuda:0")
     which = args.which.split(",")
     if "c3" in which:
@@ -68,12 +68,22 @@ def main():
             n = T * args.samples
             print(json.dumps({"kernel": "MCIntegrate_S_AB", "system": "Pb-208+Pb-208", "b": b, "events": T,
                               "samples": args.samples, "ms": ms, "event_samples_per_s": n / (ms * 1e-3),
-                              "pairs_per_s": n * 208 * 208 / (ms * 1e-3), "S_AB": float(xs.sabMean.item())}))
-        ms = timed(lambda: xs.MCIntegrate_S_AB(args.samples, 7.0, stepsize=2.2, dmax2=6.76 / 3.14159265), args.reps)
+                              # nominal = all A x B pairs of the product, including those the kernel skips (culled
+                              # as exact factors 1.0f, or behind a zero-product exit); how many it evaluates is not counted
+                              "nominal_pairs_per_s": n * 208 * 208 / (ms * 1e-3), "evaluated_pairs_per_s": None,
+                              "S_AB": float(xs.sabMean.item())}))
         n = T * args.samples
-        print(json.dumps({"kernel": "MCIntegrate_S_AB+hits", "system": "Pb-208+Pb-208", "b": 7.0, "events": T,
-                          "samples": args.samples, "ms": ms, "event_samples_per_s": n / (ms * 1e-3),
-                          "pairs_per_s": n * 208 * 208 / (ms * 1e-3), "hits": xs.hits.cpu().tolist()}))
+        for cull in ("1", "0"):
+            # product + counters at b = 7 fm: bounding boxes cull nothing and the counters forbid the zero-product
+            # exit, so with the culling off every nominal pair IS evaluated (evaluated = nominal)
+            L.check(L.lib.mcmc_set_option(b"MCMC_SAB_CULL", cull.encode()))
+            ms = timed(lambda: xs.MCIntegrate_S_AB(args.samples, 7.0, stepsize=2.2, dmax2=6.76 / 3.14159265), args.reps)
+            print(json.dumps({"kernel": "MCIntegrate_S_AB+hits", "system": "Pb-208+Pb-208", "b": 7.0, "cull": cull == "1",
+                              "events": T, "samples": args.samples, "ms": ms, "event_samples_per_s": n / (ms * 1e-3),
+                              "nominal_pairs_per_s": n * 208 * 208 / (ms * 1e-3),
+                              "evaluated_pairs_per_s": n * 208 * 208 / (ms * 1e-3) if cull == "0" else None,
+                              "hits": xs.hits.cpu().tolist()}))
+        L.lib.mcmc_set_option(b"MCMC_SAB_CULL", None)
         for b in [float(v) for v in args.inel_bs.split(",")]:
             ms = timed(lambda: xs.MCIntegrate_Inel(args.samples, b, 6.76 / 3.14159265, stepsize=2.2), args.reps)
             h = xs.hits.cpu().tolist()
