@@ -155,17 +155,17 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
                 normal = ((const Real *)p.inj_normals)[slot];
                 if constexpr (RULE != MCMC_ACCEPT_SHORTCIRCUIT) uniform = ((const Real *)p.inj_uniforms)[slot];
             }
-            bool take;
+            uint64_t took; // the wave's mask of accepting lanes
             if constexpr (PRESCALED) {
-                take = mh_step_dz<KIND, RULE, MATH>(tg, x, aux, aux2, normal, uniform); // `normal` is step * z
+                took = mh_step_dz<KIND, RULE, MATH>(tg, x, aux, aux2, normal, uniform); // `normal` is step * z
             } else if constexpr (sizeof(Real) == 4) {
                 // Metropolis.cuh:43: mul + add, two roundings
-                take = mh_step_dz<KIND, RULE, MATH>(tg, x, aux, aux2, step * normal, uniform);
+                took = mh_step_dz<KIND, RULE, MATH>(tg, x, aux, aux2, step * normal, uniform);
             } else {
                 // metropolis.hpp:36-44
                 const Real proposed = x + step * normal;
                 const Real pp = pdf_precise<KIND>(tg, proposed);
-                take = pp > aux;
+                bool take = pp > aux;
                 if (!take) {
                     if constexpr (INJ) {
                         uniform = ((const Real *)p.inj_uniforms)[(cursor * p.n_coords + coord) * nc + ch];
@@ -177,8 +177,9 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
                     x = proposed;
                     aux = pp;
                 }
+                took = __builtin_amdgcn_ballot_w64(take);
             }
-            wacc += (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take) & vmask);
+            wacc += (uint64_t)__builtin_popcountll(took & vmask);
             const Real y = x - center;
             s1 += (float)y;
             s2 = __builtin_fmaf((float)y, (float)y, s2);
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
             if constexpr (STORE) {
                 // written once, never re-read by this kernel: streaming (nt) stores keep them out of L2's way
                 if (p.samples != nullptr) __builtin_nontemporal_store(x, (Real *)p.samples + slot);
-                if (p.accept_bits != nullptr) __builtin_nontemporal_store((uint8_t)(take ? 1 : 0), p.accept_bits + slot);
+                if (p.accept_bits != nullptr)
+                    __builtin_nontemporal_store((uint8_t)((took >> lane) & 1u), p.accept_bits + slot);
             }
         };
 

@@ -319,65 +319,118 @@ __device__ __forceinline__ float mh_aux_init(const Target<float> &t, float x)
     return a;
 }
 
-// dz = proposal displacement (step * normal).
+// ---------------------------------------------------------------------
+// The accept test `lhs >= rhs` and the conditional moves `d = take ? s : d` as ONE sequence under an EXEC mask:
+// v_cmpx narrows EXEC to the accepting lanes and plain v_mov_b32 (2 issue cycles each) writes only those.
+// hipcc's own form is v_cmp (vcc) + one v_cndmask_b32_e32 per value, and a v_cndmask that reads VCC measures ~7.7
+// issue cycles on gfx950 (tools/ubench_cal.hip on MI355X, profiles/r2_ubench_cal.txt: v_cmp + 3 v_cndmask = 27 SIMD
+// cycles per wave, v_cmpx + 3 v_mov + the EXEC restore = 10).  In the kernels the gain is smaller than in those
+// pure loops and depends on occupancy: measured A/B on MI355X, chain kernel 134.4 -> 129.3 cycles per proposal and the
+// nucleon chains 1.12 -> 1.25 T proposals/s at 8 waves per SIMD; the stress kernel (2 waves per SIMD) LOST 4 % and
+// keeps hipcc's form; v_cmp_e64 into an SGPR pair + v_cndmask_e64 was slower than both (136.4 cycles).  EXEC is saved and restored inside the block, so it also works under a partial EXEC (inactive lanes read
+// as not accepting).  v_cmpx_e32 writes VCC as well on gfx9.  Returns the mask of accepting lanes.
+// No DPP instruction may follow within 5 issue slots (VALU/SALU write of EXEC -> DPP hazard, not tracked through
+// inline asm): the callers' next DPP ops are the reductions at the end of a tile / sample.
+__device__ __forceinline__ uint64_t select3_ge(float lhs, float rhs, float &d0, float s0, float &d1, float s1, float &d2, float s2)
+{
+    uint64_t mask, saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_ge_f32_e32 %[l], %[r]\n\t"
+                 "v_mov_b32_e32 %[d0], %[s0]\n\t"
+                 "v_mov_b32_e32 %[d1], %[s1]\n\t"
+                 "v_mov_b32_e32 %[d2], %[s2]\n\t"
+                 "s_mov_b64 %[m], exec\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [m] "=s"(mask), [sv] "=&s"(saved)
+                 : [l] "v"(lhs), [r] "v"(rhs), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2)
+                 : "vcc");
+    return mask;
+}
+
+__device__ __forceinline__ uint64_t select2_ge(float lhs, float rhs, float &d0, float s0, float &d1, float s1)
+{
+    uint64_t mask, saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_ge_f32_e32 %[l], %[r]\n\t"
+                 "v_mov_b32_e32 %[d0], %[s0]\n\t"
+                 "v_mov_b32_e32 %[d1], %[s1]\n\t"
+                 "s_mov_b64 %[m], exec\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [d0] "+v"(d0), [d1] "+v"(d1), [m] "=s"(mask), [sv] "=&s"(saved)
+                 : [l] "v"(lhs), [r] "v"(rhs), [s0] "v"(s0), [s1] "v"(s1)
+                 : "vcc");
+    return mask;
+}
+
+// same with a second condition `gt > 0` (the NODIV rule never moves onto p' == 0): two v_cmpx in a row AND their masks
+__device__ __forceinline__ uint64_t select2_ge_pos(float lhs, float rhs, float gt, float &d0, float s0, float &d1, float s1)
+{
+    uint64_t mask, saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_ge_f32_e32 %[l], %[r]\n\t"
+                 "v_cmpx_lt_f32_e32 0, %[g]\n\t"
+                 "v_mov_b32_e32 %[d0], %[s0]\n\t"
+                 "v_mov_b32_e32 %[d1], %[s1]\n\t"
+                 "s_mov_b64 %[m], exec\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [d0] "+v"(d0), [d1] "+v"(d1), [m] "=s"(mask), [sv] "=&s"(saved)
+                 : [l] "v"(lhs), [r] "v"(rhs), [g] "v"(gt), [s0] "v"(s0), [s1] "v"(s1)
+                 : "vcc");
+    return mask;
+}
+
+// dz = proposal displacement (step * normal).  Returns the wave's mask of accepting lanes.
 template <int KIND, int RULE, int MATH>
-__device__ __forceinline__ bool mh_step_dz(const Target<float> &t, float &x, float &aux, float &aux2, float dz,
-                                           float uniform)
+__device__ __forceinline__ uint64_t mh_step_dz(const Target<float> &t, float &x, float &aux, float &aux2, float dz,
+                                               float uniform)
 {
     const float next = x + dz;
-    bool take;
-    if constexpr (RULE == MCMC_ACCEPT_RECIP) {
+    if constexpr (MATH != MCMC_MATH_FAST) {
+        // the parity path: the reference's written expressions, hipcc's own compare + select
+        static_assert(RULE == MCMC_ACCEPT_RECIP, "precise math implements the reference's rule only");
         const float pn = pdf_eval<KIND, MATH>(t, next);
-        take = pn * aux >= uniform; // Metropolis.cuh:47
-        float inv;
-        if constexpr (MATH == MCMC_MATH_FAST) inv = __builtin_amdgcn_rcpf(pn);
-        else inv = 1 / pn; // Metropolis.cuh:50
+        const bool take = pn * aux >= uniform; // Metropolis.cuh:47
+        const float inv = 1 / pn;              // Metropolis.cuh:50
         aux = take ? inv : aux;
+        x = take ? next : x;
+        return __builtin_amdgcn_ballot_w64(take);
+    } else if constexpr (RULE == MCMC_ACCEPT_RECIP) {
+        const float pn = pdf_eval<KIND, MATH>(t, next);
+        return select2_ge(pn * aux, uniform, aux, __builtin_amdgcn_rcpf(pn), x, next); // Metropolis.cuh:47-50
     } else if constexpr (RULE == MCMC_ACCEPT_NODIV) {
         const float pn = pdf_eval<KIND, MATH>(t, next);
-        take = pn >= uniform * aux;
         // p' == 0 with p == 0 can only happen for a bad start; never move onto p' == 0
-        take = take && (pn > 0.0f);
-        aux = take ? pn : aux;
+        return select2_ge_pos(pn, uniform * aux, pn, aux, pn, x, next);
     } else if constexpr (RULE == MCMC_ACCEPT_LOG) {
         const float lpn = logpdf_fast<KIND>(t, next);
         const float lu = 0.6931471805599453f * __builtin_amdgcn_logf(uniform);
-        take = lu <= lpn - aux;
-        aux = take ? lpn : aux;
+        return select2_ge(lpn - aux, lu, aux, lpn, x, next); // log U <= log p' - log p
     } else {
         const float inf = __builtin_inff();
         if constexpr (KIND == MCMC_TARGET_WS) {
             float dn = 1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(next, t.k1, t.k0));
             dn = next < 0.0f ? inf : dn;       // p' = 0: inf on the right-hand side rejects
-            take = aux >= uniform * dn;
-            aux = take ? dn : aux;
+            return select2_ge(aux, uniform * dn, aux, dn, x, next);
         } else if constexpr (KIND == MCMC_TARGET_R2WS) {
             const float dn = 1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(next, t.k1, t.k0));
             // n' = r |r| (the |.| is a source modifier): r^2 for r >= 0; for r < 0 a negative left-hand side,
             // which fails against the non-negative right-hand side as n' = 0 would -- no v_max_f32 (4 cycles)
             const float nn = next * __builtin_fabsf(next);
-            take = nn * aux >= (uniform * aux2) * dn;
-            aux = take ? dn : aux;
-            aux2 = take ? nn : aux2;
+            return select3_ge(nn * aux, (uniform * aux2) * dn, aux, dn, aux2, nn, x, next);
         } else if constexpr (KIND == MCMC_TARGET_GAUSS) {
             float gn = next * next * t.k1;
             gn = next < 0.0f ? -inf : gn;
-            take = __builtin_amdgcn_exp2f(gn - aux) >= uniform;
-            aux = take ? gn : aux;
+            return select2_ge(__builtin_amdgcn_exp2f(gn - aux), uniform, aux, gn, x, next);
         } else {
             const float nn = next * __builtin_fabsf(next); // see R2WS
             const float gn = __builtin_fabsf(nn) * t.k1;
-            take = nn * __builtin_amdgcn_exp2f(gn - aux) >= uniform * aux2;
-            aux = take ? gn : aux;
-            aux2 = take ? nn : aux2;
+            return select3_ge(nn * __builtin_amdgcn_exp2f(gn - aux), uniform * aux2, aux, gn, aux2, nn, x, next);
         }
     }
-    x = take ? next : x;
-    return take;
 }
 
 template <int KIND, int RULE, int MATH>
-__device__ __forceinline__ bool mh_step_dz(const Target<float> &t, float &x, float &aux, float dz, float uniform)
+__device__ __forceinline__ uint64_t mh_step_dz(const Target<float> &t, float &x, float &aux, float dz, float uniform)
 {
     static_assert(RULE != MCMC_ACCEPT_CROSS, "the cross-multiplied rule carries two cached values");
     float unused = 0.0f;
@@ -385,8 +438,8 @@ __device__ __forceinline__ bool mh_step_dz(const Target<float> &t, float &x, flo
 }
 
 template <int KIND, int RULE, int MATH>
-__device__ __forceinline__ bool mh_step(const Target<float> &t, float &x, float &aux, float step, float normal,
-                                        float uniform)
+__device__ __forceinline__ uint64_t mh_step(const Target<float> &t, float &x, float &aux, float step, float normal,
+                                            float uniform)
 {
     // Metropolis.cuh:43.  Deliberately mul + add (two roundings) in every mode: with a fused
     // multiply-add the positions drift from the reference arithmetic by an ulp per accepted step.

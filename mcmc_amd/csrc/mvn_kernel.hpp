@@ -120,6 +120,7 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
                         float lu;
                         if constexpr (MATH == MCMC_MATH_FAST) lu = 0.6931471805599453f * __builtin_amdgcn_logf(u[h]);
                         else lu = logf(u[h]);
+                        // (the EXEC-masked select of device_common.hpp costs this kernel 4 %: two waves per SIMD)
                         const bool take = lu <= delta;
                         const float xn = take ? xc + dz : xc;
                         xs[i * MVN_BLOCK + tid] = xn;

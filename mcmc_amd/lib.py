@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcmc_hip.so")
+# MCMC_HIP_LIB: another build of the same library (A/B timing of kernel variants, tools/); default: the in-tree build
+LIB_PATH = os.environ.get("MCMC_HIP_LIB") or os.path.join(_HERE, "libmcmc_hip.so")
 
 TARGET_WS, TARGET_R2WS, TARGET_GAUSS, TARGET_R2GAUSS = 0, 1, 2, 3
 ACCEPT_RECIP, ACCEPT_SHORTCIRCUIT, ACCEPT_NODIV, ACCEPT_LOG, ACCEPT_CROSS = 0, 1, 2, 3, 4

@@ -18,15 +18,21 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN4mcmc12chain_kernelIfLi1ELi4ELi1ELi0ELb0ELb0EEEvNS_11ChainParamsE"  # float, R2WS, CROSS, FAST, no lags
+NLAG = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+# float, R2WS, CROSS, FAST, NLAG lags, Philox draws, no write-back, no stamps
+KERNEL = f"_ZN4mcmc12chain_kernelIfLi1ELi4ELi1ELi{NLAG}ELb0ELb0ELb0EEEvNS_11ChainParamsE"
 QUARTER = re.compile(r"^v_(exp_f32|log_f32|rcp_f32|rsq_f32|sqrt_f32|sin_f32|cos_f32)")
-HALF = re.compile(r"^v_(mad_u64_u32|mul_hi_u32|mul_lo_u32|alignbit_b32|perm_b32|bfi_b32|xad_u32|add3_u32|max_f32|min_f32|cmp_)")
+HALF = re.compile(r"^v_(mad_u64_u32|mul_hi_u32|mul_lo_u32|alignbit_b32|perm_b32|bfi_b32|xad_u32|add3_u32|max_f32|min_f32|cmp_|cmpx_)")
+# v_cndmask_b32_e32 (mask in VCC): 7.7 cycles in the v_cmp + 3 v_cndmask pattern (tools/ubench_cal.hip, profiles/r2_ubench_cal.txt)
+SLOW = {"v_cndmask_b32_e32": 7.7}
 ISOLATED = {"v_xor_b32_e32": 2.93, "v_bitop3_b32": 2.24, "v_add_f32_e32": 2.57, "v_sub_f32_e32": 2.43, "v_mul_f32_e32": 2.31, "v_fma_f32": 2.89,
             "v_fmac_f32_e32": 2.80, "v_alignbit_b32": 4.14, "v_perm_b32": 4.14, "v_mad_u64_u32": 4.29, "v_max_f32_e32": 4.08,
             "v_cmp_ge_f32_e32": 4.29}  # cycles; anything else: its class in the ideal model
 
 
 def ideal_cost(op):
+    if op in SLOW:
+        return SLOW[op]
     return 8.0 if QUARTER.match(op) else 4.0 if HALF.match(op) else 2.0
 
 
@@ -52,7 +58,12 @@ def main():
             n_mad = sum("v_mad_u64_u32" in x for x in seg)
             if best is None or n_mad > best[0]:
                 best = (n_mad, seg)
-    hist = collections.Counter(x.split()[0] for x in best[1] if x.startswith("\t") and not x.strip().startswith(";"))
+    hist = collections.Counter()
+    for x in best[1]:      # inline-asm blocks arrive as one line with embedded newlines: split them
+        for y in x.split("\n"):
+            y = y.strip()
+            if y and not y.startswith(";") and not y.startswith(".") and not y.endswith(":"):
+                hist[y.split()[0]] += 1
     valu = {k: v for k, v in hist.items() if k.startswith("v_")}
     n_valu = sum(valu.values())
     n_q = sum(v for k, v in valu.items() if QUARTER.match(k))
