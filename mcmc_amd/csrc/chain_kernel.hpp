@@ -14,7 +14,9 @@ namespace mcmc {
 
 constexpr int CHAIN_BLOCK = 256;
 constexpr int CHAIN_WAVES = CHAIN_BLOCK / 64;
-constexpr int LAGPAD = 4; // steps per lag-window group (even)
+constexpr int LAGPAD = 8; // steps per lag-window group = one draw group; the window is shifted once per group
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <typename F, int... Is>
 __device__ __forceinline__ void expand_sequence(F &&f, std::integer_sequence<int, Is...>)
@@ -57,7 +59,10 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 // STAMP: diagnostic instantiation (mcmc_chain_clock_probe) -- the same body with one s_memtime / s_memrealtime pair
 //        around the block's tile loop, written to a buffer of their own; no production launch executes a stamp
 template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, bool STORE, bool STAMP = false>
-__global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(const ChainParams p)
+#ifndef MCMC_LAG_BLOCKS_PER_CU
+#define MCMC_LAG_BLOCKS_PER_CU 3
+#endif
+__global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? MCMC_LAG_BLOCKS_PER_CU : 1) void chain_kernel(const ChainParams p)
 {
     constexpr int NL = NLAG > 0 ? NLAG : 1;
     __shared__ double sred[CHAIN_WAVES][3 + 3 * NL];
@@ -116,8 +121,18 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
         // LAGPAD steps write its samples at static indices and shift the window once per group
         // (NL/LAGPAD register moves per step instead of NL).  Kept in float: it only feeds the float
         // lag products and the head/tail sums.
-        float H[NL + LAGPAD];
-        float P[NL];
+        // Both arrays are register PAIRS (HN, NP even): on the even steps of a group the history pair
+        // (H[B+k], H[B+k+1]) = (lag k+1, lag k+2) is an aligned pair like the accumulator pair (P_k, P_k+1), so two
+        // products are ONE v_pk_fma_f32 (4.2 issue cycles against 2 x 3.1 for v_fmac_f32, tools/ubench_cal.hip); on odd
+        // steps the pairs straddle and the products are single FMAs.  Every P_k receives the same FMAs in the same
+        // order either way.  (A circular window with static slots -- no shifts at all -- needs the loop unrolled over
+        // 56 steps: 36 KB of code, and measured SLOWER, 312 against 300 cycles per proposal.)
+        constexpr int NP = (NL + 1) / 2;              // accumulator pairs; the odd tail lane is a dummy
+        constexpr int HN = (NL + LAGPAD + 2) / 2;     // history pairs (one spare slot feeds the dummy lane)
+        f32x2 H2[HN];
+        f32x2 P2[NP];
+#define MCMC_LAGH(j) H2[(j) >> 1][(j)&1]
+#define MCMC_LAGP(k) P2[(k) >> 1][(k)&1]
         // FP64 instantiation (metropolis.hpp / statistics.hpp arithmetic): the float lag products are folded into
         // FP64 at every flush (<= 128 steps), like s1 / s2.  The float kernels keep P in FP32 for the launch
         // (49 more FP64 accumulators would halve their occupancy): see mcmc_hip.h for the bound this puts on n_steps.
@@ -126,14 +141,14 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
 #pragma unroll
         for (int k = 0; k < NPD; ++k) PD[k] = 0.0;
 #pragma unroll
-        for (int k = 0; k < NL; ++k) P[k] = 0.0f;
+        for (int k = 0; k < NP; ++k) P2[k] = f32x2{0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < NL + LAGPAD; ++k) H[k] = 0.0f;
+        for (int k = 0; k < HN; ++k) H2[k] = f32x2{0.0f, 0.0f};
         if (NLAG > 0 && !p.window_start && p.ring != nullptr) {
 #pragma unroll
             for (int k = 0; k < NL; ++k)
                 if (k < (int)p.n_lags)
-                    H[LAGPAD + k] = (float)((const Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch];
+                    MCMC_LAGH(LAGPAD + k) = (float)((const Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch];
         }
 
         double S1 = 0.0, S2 = 0.0;
@@ -185,14 +200,21 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
             s2 = __builtin_fmaf((float)y, (float)y, s2);
             if constexpr (NLAG > 0) {
                 constexpr int BASE = SLOT < 0 ? LAGPAD : LAGPAD - SLOT;
+                if constexpr (SLOT >= 0 && (BASE & 1) == 0 && sizeof(Real) == 4) {
+                    const f32x2 yy = {(float)y, (float)y}; // only the low half is read (op_sel / op_sel_hi of src0 = 0)
 #pragma unroll
-                for (int k = 0; k < NL; ++k) P[k] = __builtin_fmaf((float)y, H[BASE + k], P[k]);
+                    for (int jj = 0; jj < NP; ++jj)
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(P2[jj]) : "v"(yy), "v"(H2[(BASE >> 1) + jj]));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NL; ++k) MCMC_LAGP(k) = __builtin_fmaf((float)y, MCMC_LAGH(BASE + k), MCMC_LAGP(k));
+                }
                 if constexpr (SLOT < 0) {
 #pragma unroll
-                    for (int k = NL - 1; k > 0; --k) H[LAGPAD + k] = H[LAGPAD + k - 1];
-                    H[LAGPAD] = (float)y;
+                    for (int k = NL - 1; k > 0; --k) MCMC_LAGH(LAGPAD + k) = MCMC_LAGH(LAGPAD + k - 1);
+                    MCMC_LAGH(LAGPAD) = (float)y;
                 } else {
-                    H[BASE - 1] = (float)y;
+                    MCMC_LAGH(BASE - 1) = (float)y;
                 }
             }
             if constexpr (STORE) {
@@ -211,16 +233,16 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
             if constexpr (NLAG > 0 && sizeof(Real) == 8) {
 #pragma unroll
                 for (int k = 0; k < NL; ++k) {
-                    PD[k] += (double)P[k];
-                    P[k] = 0.0f;
+                    PD[k] += (double)MCMC_LAGP(k);
+                    MCMC_LAGP(k) = 0.0f;
                 }
             }
         };
 
         // One group of 8 steps = 4 step pairs from 3 Philox blocks (device_common.hpp, packed draws).
         // FULL: every step of the group is inside [ta, tb): no range tests, static lag-window slots
-        // (the window is shifted by LAGPAD = 4 after pairs 1 and 3).  Otherwise (first / last group of a
-        // launch) each step is range-tested and shifts the window itself.
+        // (the window is shifted by LAGPAD = 8, whole register pairs, after the group).  Otherwise (first / last
+        // group of a launch) each step is range-tested and shifts the window itself.
         auto do_group = [&](auto full_tag, uint64_t g, uint64_t ta, uint64_t tb) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
             uint32_t sp[3] = {0u, 0u, 0u};
@@ -243,9 +265,10 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
                 if constexpr (FULL) {
                     one_step(std::integral_constant<int, (2 * J) & (LAGPAD - 1)>{}, t0, z0, u0);
                     one_step(std::integral_constant<int, (2 * J + 1) & (LAGPAD - 1)>{}, t0 + 1, z1, u1);
-                    if constexpr (NLAG > 0 && (J & 1) == 1) {
+                    if constexpr (NLAG > 0 && 2 * J + 2 == LAGPAD) {
+                        // slots LAGPAD .. NL+LAGPAD-1 <- slots 0 .. NL-1, pair by pair (LAGPAD is even)
 #pragma unroll
-                        for (int j = NL + LAGPAD - 1; j >= LAGPAD; --j) H[j] = H[j - LAGPAD];
+                        for (int j = (NL + LAGPAD - 1) >> 1; j >= LAGPAD / 2; --j) H2[j] = H2[j - LAGPAD / 2];
                     }
                 } else {
                     constexpr std::integral_constant<int, -1> GEN{};
@@ -292,7 +315,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
                     for (int k = 0; k < NL; ++k) {
                         if (k < (int)p.n_lags) {
                             // H[LAGPAD + k] = y_{n_lags-1-k}
-                            const double w = wave_sum(valid ? (double)H[LAGPAD + k] : 0.0);
+                            const double w = wave_sum(valid ? (double)MCMC_LAGH(LAGPAD + k) : 0.0);
                             if (lane == 0) sred[wave][3 + p.n_lags + (p.n_lags - 1 - k)] += (double)w;
                         }
                     }
@@ -306,7 +329,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
 #pragma unroll
             for (int k = 0; k < NL; ++k)
                 if (k < (int)p.n_lags)
-                    ((Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch] = (Real)H[LAGPAD + k];
+                    ((Real *)p.ring)[((uint64_t)coord * p.n_lags + k) * nc + ch] = (Real)MCMC_LAGH(LAGPAD + k);
         }
 
         S1acc += valid ? S1 : 0.0;
@@ -318,10 +341,10 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
             for (int k = 0; k < NL; ++k) {
                 if (k < (int)p.n_lags) {
                     // FP64 across chains: sums must not depend on how chains fall into waves / GPUs
-                    double pk_lane = (double)P[k];
+                    double pk_lane = (double)MCMC_LAGP(k);
                     if constexpr (sizeof(Real) == 8) pk_lane += PD[k];
                     const double pk = wave_sum(valid ? pk_lane : 0.0);
-                    const double zk = wave_sum(valid ? (double)H[LAGPAD + k] : 0.0);
+                    const double zk = wave_sum(valid ? (double)MCMC_LAGH(LAGPAD + k) : 0.0);
                     if (lane == 0) {
                         sred[wave][3 + k] += (double)pk;
                         sred[wave][3 + 2 * p.n_lags + k] += (double)zk;
@@ -347,6 +370,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? 3 : 1) void chain_kernel(co
         for (int w = 0; w < CHAIN_WAVES; ++w) tot += sred[w][tid];
         p.partials[((uint64_t)coord * gridDim.x + blockIdx.x) * len + tid] = tot;
     }
+#undef MCMC_LAGP
+#undef MCMC_LAGH
     if constexpr (STAMP) {
         const uint64_t dc = __builtin_amdgcn_s_memtime() - stamp_c;
         const uint64_t dr = __builtin_amdgcn_s_memrealtime() - stamp_r;

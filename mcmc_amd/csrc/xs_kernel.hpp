@@ -450,6 +450,16 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     uint32_t h_coll = 0, h_inel = 0, h_part = 0;
     const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
 
+    // After the target table above, every LDS word an event touches is private to the event's G lanes, and those lie
+    // in ONE wavefront (G divides 64).  A wave's LDS operations execute in program order, so between one lane's
+    // store and another lane's load of the same event a scheduling fence is all that is needed -- no workgroup
+    // barrier: the four waves of a block no longer wait for each other's events (early exits, culled events).
+    auto event_sync = []() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
     // Exact pair culling (one event per wavefront).  A pair farther apart than cull_d contributes the factor
     // exactly 1.0f (Gamma <= 2^-25 is absorbed by the rounding of 1 - Gamma, in the reference's arithmetic too)
     // and is never a black-disk hit, so an A nucleon outside the bounding box of B grown by cull_d -- and then a
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                 }
                 stE[n] = s;
             }
-            __syncthreads();
+            event_sync();
             if constexpr (LAZY) {
                 if (lazy) {
                     const uint32_t nAp = 2u * GA < p.nA ? 2u * GA : p.nA;
@@ -714,16 +724,16 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
             }
             if (needA) pair_sweep(trAE);
             if constexpr (HITS) {
-                __syncthreads();
+                event_sync();
                 if (actA) count_marks();
-                __syncthreads();
+                event_sync();
             }
             if (needB) pair_sweep(trBE);
             if constexpr (HITS) {
-                __syncthreads();
+                event_sync();
                 if (actB) count_marks();
             }
-            __syncthreads();
+            event_sync();
         }
     }
 

@@ -47,6 +47,14 @@ struct op_cmp_fma_cnd3 { static constexpr const char *name = "v_cmp, 4 v_fma, 3 
 struct op_cmpx_mov3 { static constexpr const char *name = "v_cmpx (exec) + 3 v_mov + s_mov exec"; static constexpr int n = 4; };
 struct op_sub_ashr_bitop3 { static constexpr const char *name = "v_sub, v_ashrrev, 3 v_bitop3 0xCA (sign-mask select)"; static constexpr int n = 5; };
 struct op_cmp_sgpr_cnd3 { static constexpr const char *name = "v_cmp_e64 -> SGPR pair + 3 v_cndmask_e64"; static constexpr int n = 4; };
+struct op_pk_fma { static constexpr const char *name = "v_pk_fma_f32 (2 FMAs)"; static constexpr int n = 1; };
+struct op_pk_fma_bcast { static constexpr const char *name = "v_pk_fma_f32 op_sel broadcast of src0.lo (2 FMAs)"; static constexpr int n = 1; };
+struct op_dot2_f16 { static constexpr const char *name = "v_dot2_f32_f16 (2 MACs, f32 accumulate)"; static constexpr int n = 1; };
+struct op_dot2c_f16 { static constexpr const char *name = "v_dot2c_f32_f16 (2 MACs, f32 accumulate, VOP2)"; static constexpr int n = 1; };
+struct op_and_or { static constexpr const char *name = "v_and_or_b32"; static constexpr int n = 1; };
+struct op_lshr { static constexpr const char *name = "v_lshrrev_b32"; static constexpr int n = 1; };
+struct op_cvt_u32 { static constexpr const char *name = "v_cvt_f32_u32"; static constexpr int n = 1; };
+struct op_bfe { static constexpr const char *name = "v_bfe_u32"; static constexpr int n = 1; };
 struct op_fma12 { static constexpr const char *name = "12 v_fma (reference for the mixed loop)"; static constexpr int n = 12; };
 
 template <typename OP>
@@ -65,6 +73,10 @@ __global__ __launch_bounds__(256) void cal(unsigned *out, unsigned seed)
 #pragma unroll
     for (int i = 0; i < ILP; ++i) lo32[i] = threadIdx.x + i, hi32[i] = threadIdx.x * 3u + i, f0[i] = 0x3f000000u + i, f1[i] = 0x3e800000u + i;
     unsigned long long mask = 0x5555aaaa0f0f3333ull ^ seed;
+    unsigned long long w2[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) w2[i] = 0x3f0000003e800000ull + i;
+    const unsigned long long w3 = 0x3f8000003f800001ull + seed;
     if constexpr (__is_same(OP, op_cnd_vccset)) asm volatile("v_cmp_ge_f32_e32 vcc, %0, %1" : : "v"(a[0]), "v"(b[0]) : "vcc");
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -88,6 +100,15 @@ __global__ __launch_bounds__(256) void cal(unsigned *out, unsigned seed)
                 if constexpr (__is_same(OP, op_cndmask)) asm volatile("v_cndmask_b32_e32 %0, %1, %0, vcc" : "+v"(a[i]) : "v"(b[i]) :);
                 if constexpr (__is_same(OP, op_mov)) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(a[i]) : "v"(b[i]));
                 if constexpr (__is_same(OP, op_max)) asm volatile("v_max_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+                if constexpr (__is_same(OP, op_pk_fma)) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(w[i]) : "v"(w2[i]), "v"(w3));
+                if constexpr (__is_same(OP, op_pk_fma_bcast))
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(w[i]) : "v"(w3), "v"(w2[i]));
+                if constexpr (__is_same(OP, op_dot2_f16)) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b[i]), "v"(c));
+                if constexpr (__is_same(OP, op_dot2c_f16)) asm volatile("v_dot2c_f32_f16_e32 %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c));
+                if constexpr (__is_same(OP, op_and_or)) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c));
+                if constexpr (__is_same(OP, op_lshr)) asm volatile("v_lshrrev_b32_e32 %0, 9, %0" : "+v"(a[i]));
+                if constexpr (__is_same(OP, op_cvt_u32)) asm volatile("v_cvt_f32_u32_e32 %0, %0" : "+v"(a[i]));
+                if constexpr (__is_same(OP, op_bfe)) asm volatile("v_bfe_u32 %0, %0, 9, 23" : "+v"(a[i]));
                 if constexpr (__is_same(OP, op_cnd_sgpr)) asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(a[i]) : "v"(b[i]), "s"(mask));
                 if constexpr (__is_same(OP, op_cnd_vccset)) asm volatile("v_cndmask_b32_e32 %0, %1, %0, vcc" : "+v"(a[i]) : "v"(b[i]) :);
                 if constexpr (__is_same(OP, op_cmp_cnd3))
@@ -125,6 +146,8 @@ __global__ __launch_bounds__(256) void cal(unsigned *out, unsigned seed)
 #pragma unroll
     for (int i = 0; i < ILP; ++i) acc += a[i] + (unsigned)w[i] + (unsigned)(w[i] >> 32) + lo32[i] + hi32[i] + f0[i] + f1[i];
     acc += (unsigned)mask;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) acc += (unsigned)w2[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
@@ -169,6 +192,14 @@ int main()
     run<op_cndmask>(d_out, blocks);
     run<op_mov>(d_out, blocks);
     run<op_max>(d_out, blocks);
+    run<op_pk_fma>(d_out, blocks);
+    run<op_pk_fma_bcast>(d_out, blocks);
+    run<op_dot2_f16>(d_out, blocks);
+    run<op_dot2c_f16>(d_out, blocks);
+    run<op_and_or>(d_out, blocks);
+    run<op_lshr>(d_out, blocks);
+    run<op_cvt_u32>(d_out, blocks);
+    run<op_bfe>(d_out, blocks);
     run<op_cnd_sgpr>(d_out, blocks);
     run<op_cnd_vccset>(d_out, blocks);
     run<op_cmp_cnd3>(d_out, blocks);
