@@ -39,6 +39,26 @@ $(OBJ)/%.o: $(CSRC)/%.cpp $(HDRS) | $(OBJ)
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# The same library with Philox4x32-7 (MCMC_PHILOX_ROUNDS=7): an optional performance build, not part of `all`
+OBJ7 = build/obj7
+LIB7 = mcmc_amd/libmcmc_hip_philox7.so
+OBJS7 = $(patsubst $(OBJ)/%,$(OBJ7)/%,$(OBJS))
+$(OBJ7):
+	mkdir -p $(OBJ7)
+$(OBJ7)/chain_kind_%.o: $(CSRC)/chain_kind.hip $(HDRS) | $(OBJ7)
+	$(HIPCC) $(HIPFLAGS) -DMCMC_PHILOX_ROUNDS=7 -fno-slp-vectorize -DMCMC_KIND=$* -c $< -o $@
+$(OBJ7)/sab_mode_%.o: $(CSRC)/sab_mode.hip $(HDRS) | $(OBJ7)
+	$(HIPCC) $(HIPFLAGS) -DMCMC_PHILOX_ROUNDS=7 -DMCMC_SAB_MODE=$* -c $< -o $@
+$(OBJ7)/mvn.o: $(CSRC)/mvn.hip $(HDRS) | $(OBJ7)
+	$(HIPCC) $(HIPFLAGS) -DMCMC_PHILOX_ROUNDS=7 -fno-slp-vectorize -c $< -o $@
+$(OBJ7)/%.o: $(CSRC)/%.hip $(HDRS) | $(OBJ7)
+	$(HIPCC) $(HIPFLAGS) -DMCMC_PHILOX_ROUNDS=7 -c $< -o $@
+$(OBJ7)/%.o: $(CSRC)/%.cpp $(HDRS) | $(OBJ7)
+	$(HIPCC) $(HIPFLAGS) -DMCMC_PHILOX_ROUNDS=7 -c $< -o $@
+$(LIB7): $(OBJS7)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS7)
+philox7: $(LIB7)
+
 drivers: $(LIB)
 	@if [ -f mcmc_amd/host/stepsize_main.cpp ]; then \
 	  g++ -O3 -std=c++17 -Iinclude -Imcmc_amd/host -o mcmc_amd/host/stepsize mcmc_amd/host/stepsize_main.cpp \
@@ -51,9 +71,9 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf build $(LIB) mcmc_amd/host/stepsize mcmc_amd/host/xsection
+	rm -rf build $(LIB) $(LIB7) mcmc_amd/host/stepsize mcmc_amd/host/xsection
 	$(MAKE) -C oracle clean
-.PHONY: all drivers oracle probes clean
+.PHONY: all drivers oracle probes philox7 clean
 
 # device probe of include/mcmc_distributions.h (tests/test_distributions_header.py)
 probes: tools/bin/dist_probe

@@ -170,6 +170,22 @@ def secondary(dev):
     return out
 
 
+def philox7_rate(args):
+    """The same workload with the optional Philox4x32-7 build of the library (`make philox7`; the default and every parity
+    test is Philox4x32-10): a child process with MCMC_HIP_LIB pointing at it.  None when that library is not built."""
+    lib7 = os.path.join(ROOT, "mcmc_amd", "libmcmc_hip_philox7.so")
+    if not os.path.exists(lib7) or os.environ.get("MCMC_HIP_LIB"):
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-ess",
+           "--no-secondary", "--no-clock", "--chains", str(args.chains), "--coords", str(args.coords), "--sweeps", str(args.sweeps),
+           "--rule", args.rule, "--math", args.math]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env={**os.environ, "MCMC_HIP_LIB": lib7})
+        return json.loads(r.stdout.strip().splitlines()[-1])["value"] if r.returncode == 0 else None
+    except Exception:  # noqa: BLE001 -- the headline line must not depend on this
+        return None
+
+
 def cpu_cores():
     """Threads for the CPU baseline: the box's CPU share (OMP_NUM_THREADS is set to it there), at most 16."""
     share = os.environ.get("OMP_NUM_THREADS", "")
@@ -531,6 +547,9 @@ def main(argv=None):
             out["lag49_proposals_per_sec_per_gpu"] = sub * args.coords * 1024 / (ea.elapsed_time(eb) * 1e-3)
     if rank == 0 and n_gpus == 1 and args.workload == "chain" and not args.no_secondary:
         out["secondary"] = secondary(dev)
+        p7 = philox7_rate(args)
+        if p7 is not None:
+            out["secondary"]["chain_philox4x32_7_proposals_per_s"] = p7
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         if args.workload == "chain":
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

@@ -400,6 +400,10 @@ int mcmc_set_option(const char *name, const char *value);
 
 const char *mcmc_last_error(void);
 const char *mcmc_version(void);
+/* Rounds of the Philox4x32 generator this build of the library was compiled with: 10 (default; every parity test) or
+ * 7 (`make philox7` -> libmcmc_hip_philox7.so: the fewest rounds that pass BigCrush, Salmon et al. SC'11; ~10 % more
+ * proposals/s).  The draw streams of the two builds differ; each is pinned by Random123's known-answer vectors.   */
+int mcmc_philox_rounds(void);
 int mcmc_device_count(void);
 
 #ifdef __cplusplus

@@ -23,10 +23,18 @@ struct u32x4 {
     uint32_t x, y, z, w;
 };
 
+// MCMC_PHILOX_ROUNDS: 10 (Philox4x32-10, the default and the parity path) or 7 (Philox4x32-7, the fewest rounds that
+// pass BigCrush per Salmon et al.; `make philox7` builds it as a separate library, bench.py reports its rate beside
+// the default's).  Both are pinned by Random123's known-answer vectors (tests/test_oracle_pinning.py).
+#ifndef MCMC_PHILOX_ROUNDS
+#define MCMC_PHILOX_ROUNDS 10
+#endif
+static_assert(MCMC_PHILOX_ROUNDS == 10 || MCMC_PHILOX_ROUNDS == 7, "Philox4x32 with 10 or 7 rounds");
+
 __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MCMC_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
         u32x4 n;

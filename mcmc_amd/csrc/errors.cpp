@@ -25,7 +25,13 @@ int set_hip_error(hipError_t e, const char *file, int line)
 } // namespace mcmc
 
 extern "C" const char *mcmc_last_error(void) { return g_err; }
-extern "C" const char *mcmc_version(void) { return "mcmc_hip 0.1 (gfx950)"; }
+#ifndef MCMC_PHILOX_ROUNDS
+#define MCMC_PHILOX_ROUNDS 10
+#endif
+#define MCMC_STR2(x) #x
+#define MCMC_STR(x) MCMC_STR2(x)
+extern "C" const char *mcmc_version(void) { return "mcmc_hip 0.2 (gfx950, philox4x32-" MCMC_STR(MCMC_PHILOX_ROUNDS) ")"; }
+extern "C" int mcmc_philox_rounds(void) { return MCMC_PHILOX_ROUNDS; }
 extern "C" int mcmc_device_count(void)
 {
     int n = 0;

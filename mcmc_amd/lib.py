@@ -94,7 +94,7 @@ EXPORTS = [
     "mcmc_Average_f64", "mcmc_Variance_f64", "mcmc_AutoCorrelation_f64", "mcmc_cross_sections",
     "mcmc_config_default", "mcmc_create", "mcmc_destroy", "mcmc_warmup", "mcmc_integrate_r2",
     "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_run_all", "mcmc_set_option", "mcmc_run_inel_scan", "mcmc_init_from_pdf", "mcmc_get_state", "mcmc_wait",
-    "mcmc_stepsize_run", "mcmc_tune_stepsize", "mcmc_isotope", "mcmc_last_error", "mcmc_version", "mcmc_device_count",
+    "mcmc_stepsize_run", "mcmc_tune_stepsize", "mcmc_isotope", "mcmc_last_error", "mcmc_version", "mcmc_philox_rounds", "mcmc_device_count",
 ]
 
 
@@ -175,6 +175,7 @@ def _load():
     lib.mcmc_last_error.restype = C.c_char_p
     lib.mcmc_version.restype = C.c_char_p
     lib.mcmc_device_count.restype = C.c_int
+    lib.mcmc_philox_rounds.restype = C.c_int
     return lib
 
 

@@ -36,11 +36,16 @@
 /* Philox4x32-10 (Random123).  Not in the reference: the reference uses
  * cuRAND XORWOW (xsection/include/Metropolis.cuh:23,43,47), which is
  * third-party and unpinned; the build replaces it by this counter RNG.  */
+/* Rounds: 10 by default (Philox4x32-10); orc_set_philox_rounds(7) makes every draw function of this file follow
+ * the library's MCMC_PHILOX_ROUNDS=7 build (Philox4x32-7, also a Random123 configuration with its own vectors). */
+static int orc_philox_rounds = 10;
+ORC_API void orc_set_philox_rounds(int rounds) { orc_philox_rounds = rounds; }
+
 ORC_API void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < orc_philox_rounds; ++round) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

@@ -66,6 +66,9 @@ class Oracle:
         self.lib = load_oracle()
 
     # --- RNG -----------------------------------------------------------
+    def set_philox_rounds(self, rounds):
+        self.lib.orc_set_philox_rounds(C.c_int(int(rounds)))
+
     def philox(self, ctr, key):
         c = (C.c_uint32 * 4)(*ctr)
         k = (C.c_uint32 * 2)(*key)

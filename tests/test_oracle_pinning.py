@@ -39,6 +39,26 @@ def test_philox_known_answers(oracle, ctr, key, expect):
     assert tuple(oracle.philox(ctr, key)) == expect
 
 
+# Random123 v1.09 kat_vectors, philox4x32 7 rounds (the library's optional MCMC_PHILOX_ROUNDS=7 build)
+PHILOX7_KAT = [
+    ((0, 0, 0, 0), (0, 0), (0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48)),
+    ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662)),
+    ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+     (0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,expect", PHILOX7_KAT)
+def test_philox7_known_answers(ctr, key, expect):
+    from oracle_lib import Oracle
+    o = Oracle()            # its own handle: the round count is a process-wide switch of the oracle library
+    o.set_philox_rounds(7)
+    try:
+        assert tuple(o.philox(ctr, key)) == expect
+    finally:
+        o.set_philox_rounds(10)
+
+
 @pytest.mark.parametrize("step", [0.5, 2.5, 5.0])
 def test_a1_trajectory_matches_reference_golden(oracle, step):
     """metropolis.hpp:28-50 under injected draws: every sample bit for bit, acceptance ratio,
