@@ -469,10 +469,11 @@ def main(argv=None):
             # HBM bytes per launch: NOT measured in this run -- the committed PMC passes of this same workload
             # (tools/gpu_profile.sh; FETCH_SIZE / WRITE_SIZE in their own runs, FETCH doubled per MI355X_MICROARCH.md)
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_chain_kernel_v6.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_chain_kernel.json")))
                 if args.chains == 1 << 24 and args.coords == 3 and args.lags == 0:
                     roof["traffic"] = pm["derived"]["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r1_pmc_chain_kernel_v6.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; not this run)"
+                    roof["traffic_source"] = ("profiles/r2_pmc_chain_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                              "this workload, tools/gpu_profile.sh; not measured in this run)")
             except (OSError, KeyError, ValueError):
                 pass
             roof["note"] = ("FP32 VALU-issue-bound (state in registers, no per-step HBM traffic). achieved = 24 algorithmic "
@@ -519,7 +520,14 @@ def main(argv=None):
                     valu.update({"ideal_issue_cycles": mix["issue_cycles_per_wave_proposal_ideal"],
                                  "frac_of_ideal_issue": mix["issue_cycles_per_wave_proposal_ideal"] / cyc,
                                  "valu_insts_per_proposal": mix["valu_insts_per_proposal"],
-                                 "isa_mix_source": f"profiles/{mix_file} (static, tools/isa_mix.py)"})
+                                 "isa_mix_source": f"profiles/{mix_file} (static, tools/isa_mix.py; 2 / 4 / 8 cycles per class)"})
+                    cal = json.load(open(os.path.join(ROOT, "profiles", "r2_valu_busy_calibrated.json")))
+                    for k, e in cal["kernels"].items():
+                        if k.startswith("chain:") and "static_mix" in e:
+                            c = e["static_mix"]["calibrated_issue_cycles_per_wave_proposal"]
+                            valu.update({"calibrated_issue_cycles": c, "frac_of_calibrated_issue": c / cyc,
+                                         "calibration_source": "profiles/r2_valu_busy_calibrated.json (per-instruction issue costs "
+                                                               "from pure-instruction loops under rocprofv3 counters)"})
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"]["valu_issue"] = valu

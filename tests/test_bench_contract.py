@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r1_bench_v*.json, produced by `python bench.py` on the GPU box) carries every
+"""The committed bench line (profiles/r2_bench_v*.json, produced by `python bench.py` on the GPU box) carries every
 field the measurement contract asks for; and bench.py refuses to run without a GPU instead of falling back."""
 import glob
 import json
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_committed_bench_line_has_the_contract_fields():
     import re
-    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r1_bench_v*.json")) if re.search(r"r1_bench_v\d+\.json$", f)]
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r2_bench_v*.json")) if re.search(r"r2_bench_v\d+\.json$", f)]
     files.sort(key=lambda f: int(re.search(r"_v(\d+)\.json$", f).group(1)))
     assert files, "no bench line under profiles/"
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])

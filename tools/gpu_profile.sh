@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ess --no-secondary $*"
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ess --no-secondary --no-clock $*"
 
 run() { # name, rocprof args...
     local name=$1; shift

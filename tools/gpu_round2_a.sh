@@ -9,7 +9,7 @@ cd "$ROOT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > "$OUT/pytest_gpu.log" 2>&1
 rc=$?; tail -n 5 "$OUT/pytest_gpu.log"; [ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python -u -m pytest tests/wip_no_alloc.py -m gpu -x -q --timeout 120 --timeout-method thread > "$OUT/pytest_noalloc.log" 2>&1
+timeout -k 10 300 python -u -m pytest tests/test_zz_no_alloc.py -m gpu -x -q --timeout 120 --timeout-method thread > "$OUT/pytest_noalloc.log" 2>&1
 rc=$?; tail -n 5 "$OUT/pytest_noalloc.log"; [ $rc -eq 0 ] || exit $rc
 timeout -k 10 300 python -u bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 rc=$?; tail -c 1500 "$OUT/bench_n1.json"; [ $rc -eq 0 ] || { tail -n 20 "$OUT/bench_n1.err"; exit $rc; }
