@@ -1,12 +1,30 @@
 // mvn.hip -- Layer A.3: many chains on a correlated Gaussian target with tridiagonal precision
 // (the BASELINE "stress" configuration), host side: checks, launch, fixed-order reduction,
 // finalisation of the lag-L autocorrelation.
+#include <cstdlib>
+
 #include "host_common.hpp"
 #include "mvn_kernel.hpp"
 
 using namespace mcmc;
 
+namespace mcmc {
+int g_mvn_reg = -1; // MCMC_MVN_REG: 0 / 1 force the LDS / the register kernel where it applies (mcmc_set_option)
+}
+
 namespace {
+
+// Register-resident kernel: the stress configuration's own shape only
+bool mvn_reg_applies(const mcmc_mvn_args *a)
+{
+    if (a->dim != MVN_REG_DIM || a->observable != 0 || a->inj || a->samples_full || a->accept_bits) return false;
+    static const int env = [] {
+        const char *v = std::getenv("MCMC_MVN_REG");
+        return v && v[0] == '0' ? 0 : v && v[0] == '1' ? 1 : -1;
+    }();
+    const int sel = g_mvn_reg >= 0 ? g_mvn_reg : env;
+    return sel != 0;
+}
 
 uint32_t mvn_grid(uint64_t n_chains)
 {
@@ -88,6 +106,15 @@ extern "C" int mcmc_mvn_run(const mcmc_mvn_args *a, void *stream)
 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(mvn_grid(a->n_chains)), block(MVN_BLOCK);
+    if (mvn_reg_applies(a)) {
+        if (a->math_mode == MCMC_MATH_FAST) hipLaunchKernelGGL(mvn_reg_kernel<MCMC_MATH_FAST>, grid, block, 0, s, p);
+        else hipLaunchKernelGGL(mvn_reg_kernel<MCMC_MATH_PRECISE>, grid, block, 0, s, p);
+        MCMC_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(mvn_finalize_kernel, dim3(MVN_STATS), dim3(256), 0, s, (const double *)a->workspace, a->stats,
+                           (int)grid.x);
+        MCMC_HIP_CHECK(hipGetLastError());
+        return MCMC_OK;
+    }
     const size_t lds = sizeof(float) * (size_t)a->dim * MVN_BLOCK;
     const bool inj = a->inj != nullptr, store = a->samples_full != nullptr || a->accept_bits != nullptr;
 #define MCMC_MVN_LAUNCH(MATH, INJ, STORE)                                                                        \

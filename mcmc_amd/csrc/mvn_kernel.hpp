@@ -18,6 +18,7 @@
 // 241 VGPRs, same occupancy, 3 % faster without and 2x slower with full write-back -- not kept.)
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "device_common.hpp"
 
@@ -29,6 +30,12 @@ constexpr uint32_t TAG_MVN = 3u;
 constexpr int MVN_STATS = 6; // S1, S2, accepts, P_L, HEAD, TAIL
 
 typedef float f8 __attribute__((ext_vector_type(8)));
+
+template <typename F, int... Is>
+__device__ __forceinline__ void mvn_expand(F &&f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
 
 struct MvnParams {
     // band of Q, eight coordinates per vector so that one group of 8 proposals fetches its
@@ -166,6 +173,139 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
         if (valid)
             for (uint32_t j = 0; j < D; ++j) p.state[(uint64_t)j * nc + ch] = xs[j * MVN_BLOCK + tid];
 
+        const double r0 = wave_sum(valid ? S1 : 0.0), r1 = wave_sum(valid ? S2 : 0.0), r3 = wave_sum(valid ? PL : 0.0),
+                     r4 = wave_sum(valid ? HEAD : 0.0), r5 = wave_sum(valid ? TAIL : 0.0);
+        if (lane == 0) {
+            sred[wave][0] += r0;
+            sred[wave][1] += r1;
+            sred[wave][2] += (double)wacc;
+            sred[wave][3] += r3;
+            sred[wave][4] += r4;
+            sred[wave][5] += r5;
+        }
+    }
+    __syncthreads();
+    if (tid < MVN_STATS) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < MVN_BLOCK / 64; ++w) tot += sred[w][tid];
+        p.partials[(uint64_t)blockIdx.x * MVN_STATS + tid] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------
+// Register-resident twin of mvn_kernel for the stress configuration itself (D = 64, observable = coordinate 0,
+// Philox draws, no full-state / accept-flag write-back): the chain's 64 coordinates live in VGPRs, the sweep is
+// unrolled over them (static register indices), nothing goes through LDS.  LDS capacity (256 B per chain) holds the
+// LDS kernel at two waves per SIMD, where its serial dependence x_{i-1} -> x_i is not hidden (rocprofv3: 63-78 % VALU
+// issue occupancy, no LDS stall, profiles/r2_valu_busy_calibrated.json); this kernel is compiled for four.
+// Same draws, same expressions in the same order: states, statistics and write-back are bit-identical to mvn_kernel's
+// (tests/test_gpu_mvn.py compares the two).
+constexpr int MVN_REG_DIM = 64;
+
+template <int MATH>
+__global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p)
+{
+    __shared__ double sred[MVN_BLOCK / 64][MVN_STATS];
+    // the band of Q per coordinate as (Q_ii, Q_ii / 2, Q_i,i+1, Q_i,i-1): one broadcast ds_read_b128 per proposal.
+    // (Left in the kernel arguments, the unrolled sweep keeps all 192 values in SGPRs and spills them through
+    // v_writelane / v_readlane: 5 such instructions per proposal.)
+    __shared__ float4 qc[MVN_REG_DIM];
+    constexpr int D = MVN_REG_DIM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint64_t nc = p.n_chains;
+    if (tid < (MVN_BLOCK / 64) * MVN_STATS) (&sred[0][0])[tid] = 0.0;
+    if (tid < D) {
+        const float *qd = reinterpret_cast<const float *>(p.q_diag), *qh = reinterpret_cast<const float *>(p.q_half),
+                    *qo = reinterpret_cast<const float *>(p.q_off);
+        qc[tid] = make_float4(qd[tid], qh[tid], qo[tid], tid > 0 ? qo[tid - 1] : 0.0f);
+    }
+    __syncthreads();
+
+    const float scale2 = -1.3862943611198906f * p.step * p.step;
+    const uint64_t ta = p.step_offset, tb = p.step_offset + p.n_steps;
+
+    for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        const uint64_t chain = (uint64_t)tile * MVN_BLOCK + tid;
+        const bool valid = chain < nc;
+        const uint64_t ch = valid ? chain : 0;
+        const uint64_t gid = p.chain_offset + ch;
+        float xr[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) xr[j] = p.state[(uint64_t)j * nc + ch];
+
+        double S1 = 0, S2 = 0, PL = 0, HEAD = 0, TAIL = 0;
+        float s1 = 0, s2 = 0, pl = 0, hd = 0, tl = 0;
+        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+        uint64_t wacc = 0;
+
+        uint32_t row = p.ring_row0;
+#pragma unroll 1
+        for (uint64_t t = ta; t < tb; ++t) {
+            const uint64_t n0 = t * D;
+            auto group = [&](auto gi_tag) __attribute__((always_inline)) {
+                constexpr int GI = decltype(gi_tag)::value;
+                const uint64_t g = (n0 >> 3) + GI;
+                uint32_t sp[3] = {0u, 0u, 0u};
+                auto body = [&](auto j_tag) __attribute__((always_inline)) {
+                    constexpr int J = decltype(j_tag)::value;
+                    float z[2], u[2];
+                    const u32x4 w = pair_words_tag<J>(p.seed, gid, 0u, g, TAG_MVN, sp);
+                    pair_draws_f32<MATH, MATH == MCMC_MATH_FAST>(w, scale2, z[0], z[1], u[0], u[1]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        constexpr int I0 = GI * 8 + 2 * J;
+                        const int i = I0 + h; // static after unrolling
+                        const float dz = MATH == MCMC_MATH_FAST ? z[h] : p.step * z[h];
+                        const float xm = i > 0 ? xr[i > 0 ? i - 1 : 0] : 0.0f;
+                        const float xc = xr[i];
+                        const float xp = xr[i + 1 < D ? i + 1 : D - 1];
+                        const float4 q = qc[i]; // Q_ii, Q_ii / 2, Q_i,i+1, Q_i,i-1 (0 for i = 0)
+                        const float qd = q.x, orr = q.z, olm = q.w;
+                        const float hsum = qd * xc + olm * xm + orr * xp;
+                        const float t1 = hsum + q.y * dz;
+                        const float delta = -(dz * t1);
+                        float lu;
+                        if constexpr (MATH == MCMC_MATH_FAST) lu = 0.6931471805599453f * __builtin_amdgcn_logf(u[h]);
+                        else lu = logf(u[h]);
+                        const bool take = lu <= delta;
+                        xr[i] = take ? xc + dz : xc;
+                        wacc += (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take) & vmask);
+                    }
+                };
+                body(std::integral_constant<int, 0>{});
+                body(std::integral_constant<int, 1>{});
+                body(std::integral_constant<int, 2>{});
+                body(std::integral_constant<int, 3>{});
+                // the draws do not depend on the state, so the scheduler would hoist all 24 Philox blocks of a sweep
+                // to its top (243 VGPRs): keep each group of 8 proposals to itself
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            mvn_expand(group, std::make_integer_sequence<int, D / 8>{});
+            // the observable (coordinate 0), its statistics and the lag-L product through the HBM ring: as mvn_kernel
+            const float xo = xr[0];
+            const float y = xo - p.center;
+            s1 += y;
+            s2 = __builtin_fmaf(y, y, s2);
+            const uint64_t w = t - p.window_begin;
+            float *slot_ring = p.ring + (uint64_t)row * nc + ch;
+            row = row + 1 == p.lag ? 0u : row + 1;
+            if (w >= p.lag) pl = __builtin_fmaf(y, *slot_ring, pl);
+            else hd += y;
+            if (t + p.lag >= p.window_end) tl += y;
+            if (valid) *slot_ring = y;
+            if (p.samples_obs != nullptr && valid) p.samples_obs[(t - ta) * nc + ch] = xo;
+            if (((t - ta) & 127u) == 127u) {
+                S1 += (double)s1, S2 += (double)s2, PL += (double)pl, HEAD += (double)hd, TAIL += (double)tl;
+                s1 = s2 = pl = hd = tl = 0.0f;
+            }
+        }
+        S1 += (double)s1, S2 += (double)s2, PL += (double)pl, HEAD += (double)hd, TAIL += (double)tl;
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) p.state[(uint64_t)j * nc + ch] = xr[j];
+        }
         const double r0 = wave_sum(valid ? S1 : 0.0), r1 = wave_sum(valid ? S2 : 0.0), r3 = wave_sum(valid ? PL : 0.0),
                      r4 = wave_sum(valid ? HEAD : 0.0), r5 = wave_sum(valid ? TAIL : 0.0);
         if (lane == 0) {

@@ -21,6 +21,10 @@ int launch_sab_mode_3(const mcmc_xs_args *, const XsParams &, int G, size_t lds,
 int launch_sab_mode_4(const mcmc_xs_args *, const XsParams &, int G, size_t lds, bool all_r2ws, hipStream_t);
 } // namespace mcmc
 
+namespace mcmc {
+extern int g_mvn_reg; // mvn.hip
+}
+
 namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -280,8 +284,12 @@ bool sab_small_applies(const mcmc_xs_args *a, bool product_only, const SabPlan &
 extern "C" int mcmc_set_option(const char *name, const char *value)
 {
     if (!name) return set_error(MCMC_EINVAL, "null option name");
+    if (std::strcmp(name, "MCMC_MVN_REG") == 0) { // stress target: 0 / 1 = LDS / register kernel, NULL = default
+        g_mvn_reg = value && value[0] == '0' ? 0 : value && value[0] == '1' ? 1 : -1;
+        return MCMC_OK;
+    }
     if (std::strcmp(name, "MCMC_SAB_CULL") && std::strcmp(name, "MCMC_SAB_SMALL") && std::strcmp(name, "MCMC_SAB_PLAN"))
-        return set_error(MCMC_EINVAL, "unknown option (MCMC_SAB_CULL, MCMC_SAB_SMALL, MCMC_SAB_PLAN)");
+        return set_error(MCMC_EINVAL, "unknown option (MCMC_SAB_CULL, MCMC_SAB_SMALL, MCMC_SAB_PLAN, MCMC_MVN_REG)");
     (void)sab_options(); // the environment first, so that this call wins
     std::lock_guard<std::mutex> lock(opt_mutex);
     parse_option(opt_state, name, value);

@@ -170,3 +170,31 @@ def test_mvn_stress_configuration_full_size(dev):
     assert summ["rho_lag"] == pytest.approx(cov / var, abs=2e-5)
     assert abs(summ["rho_lag"]) < 0.02          # lag 1000 >> tau_int of one coordinate of the AR(1) target
     assert 0.2 < summ["acceptance"] < 0.9
+
+
+@pytest.mark.parametrize("mode", ["fast", "precise"])
+def test_mvn_register_kernel_equals_lds_kernel(dev, mode):
+    """The stress configuration's own shape (64-D, observable 0, Philox draws, observable write-back only) takes a
+    kernel with the chain's coordinates in registers.  Same draws, same expressions in the same order as the LDS
+    kernel: states, the six statistics, the observable series and the lag ring are bit-identical -- for a ragged chain
+    count over several tiles, two launches of one window, and a launch that starts mid-way through a draw group."""
+    from mcmc_amd import lib as L
+    dim, N, lag = 64, 2048 * 3 + 77, 5
+    out = []
+    try:
+        for reg in ("1", "0"):
+            L.check(L.lib.mcmc_set_option(b"MCMC_MVN_REG", reg.encode()))
+            eng, _, _ = _engine(dev, N, dim, 0.9, 0.8, lag, x0=0.3, seed=21, chain_offset=555, center=0.1,
+                                math_mode=L.MATH_FAST if mode == "fast" else L.MATH_PRECISE)
+            eng.run(3, window=(0, 3 + lag))
+            w = (eng.steps_done, eng.steps_done + 40)
+            obs = torch.empty((40, N), dtype=torch.float32, device=dev)
+            s1 = eng.run(13, window=w, samples_obs=obs[:13]).clone()
+            s2 = eng.run(27, window=w, samples_obs=obs[13:]).clone()
+            torch.cuda.synchronize()
+            out.append((eng.state.clone(), eng.ring.clone(), obs.clone(), s1, s2))
+    finally:
+        L.lib.mcmc_set_option(b"MCMC_MVN_REG", None)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    assert out[0][3][2].item() > 0 and out[0][2].abs().max().item() > 0

@@ -48,7 +48,11 @@ def main():
         alg = n * (K * bytes_per + 2 * 4 * D)
         print(json.dumps({"kernel": "mvn_kernel", "variant": name, "chains": n, "dim": D, "lag": args.lag, "sweeps": K,
                           "ms": ms, "proposals_per_s": n * D * K / (ms * 1e-3), "sweeps_per_s": n * K / (ms * 1e-3),
-                          "algorithmic_bytes": alg, "hbm_GBps": alg / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBps": alg / (ms * 1e-3) / 8e12}))
+                          "algorithmic_bytes": alg, "hbm_GBps": alg / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBps": alg / (ms * 1e-3) / 8e12,
+                          # the other bound: 22 algorithmic FP32 flop per single-coordinate update against 157.3 TFLOP/s; the
+                          # kernel is VALU-issue-bound (profiles/r2_valu_busy_calibrated.json), not HBM-bound as configs[4] assumes
+                          "valu_TFLOPs": 22.0 * n * D * K / (ms * 1e-3) / 1e12, "valu_frac_of_157TFLOPs": 22.0 * n * D * K / (ms * 1e-3) / 157.3e12,
+                          "bound": "valu issue"}))
 
 
 if __name__ == "__main__":
