@@ -348,7 +348,7 @@ class NucleonWorkload:
 
 
 class StressWorkload:
-    kernel = "mcmc::mvn_kernel"
+    kernel = "mcmc::mvn_reg_kernel"   # the 64-D configuration runs the register-resident kernel
 
     def __init__(self, args, rank, world, dev):
         import torch

@@ -31,8 +31,12 @@ def main():
     obs = torch.empty((K, n), dtype=torch.float32, device=dev)
     full = torch.empty((K, D, n), dtype=torch.float32, device=dev)
     big = (0, 1 << 40)
-    for name, kw, bytes_per in (("observable write-back + lag ring", dict(samples_obs=obs), 12),
-                                ("full-state SoA write-back + lag ring", dict(samples_obs=obs, samples_full=full), 12 + 4 * D)):
+    variants = [("mvn_kernel", "0", "observable write-back + lag ring", dict(samples_obs=obs), 12),
+                ("mvn_kernel", "0", "full-state SoA write-back + lag ring", dict(samples_obs=obs, samples_full=full), 12 + 4 * D)]
+    if D == 64:   # the register-resident kernel exists for the stress configuration's own shape only
+        variants.insert(0, ("mvn_reg_kernel", "1", "observable write-back + lag ring", dict(samples_obs=obs), 12))
+    for kernel, reg, name, kw, bytes_per in variants:
+        L.check(L.lib.mcmc_set_option(b"MCMC_MVN_REG", reg.encode()))
         eng.run(K, window=big, **kw)
         torch.cuda.synchronize()
         ts = []
@@ -46,7 +50,7 @@ def main():
         ms = sorted(ts)[len(ts) // 2]
         # state load + store once per launch is part of the traffic too
         alg = n * (K * bytes_per + 2 * 4 * D)
-        print(json.dumps({"kernel": "mvn_kernel", "variant": name, "chains": n, "dim": D, "lag": args.lag, "sweeps": K,
+        print(json.dumps({"kernel": kernel, "variant": name, "chains": n, "dim": D, "lag": args.lag, "sweeps": K,
                           "ms": ms, "proposals_per_s": n * D * K / (ms * 1e-3), "sweeps_per_s": n * K / (ms * 1e-3),
                           "algorithmic_bytes": alg, "hbm_GBps": alg / (ms * 1e-3) / 1e9, "hbm_frac_of_8TBps": alg / (ms * 1e-3) / 8e12,
                           # the other bound: 22 algorithmic FP32 flop per single-coordinate update against 157.3 TFLOP/s; the

@@ -70,7 +70,7 @@ def main():
     out["class_costs_used"] = dict(c_cls, other_low=other_lo, other_high=other_hi,
                                    note="INT32 / CVT not calibrated by a loop of their own: 2.5 / 4.2 assumed (both < 6 % of any kernel)")
 
-    for tag, want in (("chain", "chain_kernel"), ("lag49", "chain_kernel"), ("stress", "mvn_kernel"), ("sab", "sab_kernel|xs_chain_kernel")):
+    for tag, want in (("chain", "chain_kernel"), ("lag49", "chain_kernel"), ("stress", "mvn_(reg_)?kernel"), ("sab", "sab_kernel|xs_chain_kernel")):
         A_, B_, C_, T_ = load(tag + "_a"), load(tag + "_b"), load(tag + "_c"), trace(tag + "_trace")
         for k, A in A_.items():
             if not re.search(want, k) or A.get("SQ_INSTS_VALU", 0) < 1e6:
