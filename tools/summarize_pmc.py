@@ -28,15 +28,24 @@ kern_ms = None
 for r in csv.DictReader(open(os.path.join(base, "trace", "trace_kernel_stats.csv"))):
     if "chain_kernel" in r["Name"]:
         kern_ms = float(r["AverageNs"]) * 1e-6
+# per launch, in launch order: the trace run uses bench.py's default 2 warm-up + 10 timed launches
+launches = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+                  for r in csv.DictReader(open(os.path.join(base, "trace", "trace_kernel_trace.csv"))) if "chain_kernel" in r["Kernel_Name"])
+launch_ms = [d for _, d in launches]
+warm = bench.get("warmup", 0)
+timed_ms = sum(launch_ms[warm:]) / max(len(launch_ms[warm:]), 1)
 p = out["per_launch"]
 props = cfg["chains_per_gpu"] * cfg["coords"] * cfg["sweeps_per_step"]
 cycles = p["GRBM_GUI_ACTIVE"] / 8
 out["derived"] = {
     "kernel_ms_kernel_trace": kern_ms,
+    "kernel_ms_per_launch_kernel_trace": launch_ms,
+    "kernel_ms_timed_launches_kernel_trace": timed_ms,
+    "kernel_ms_bench_hip_events_same_run": bench["roofline"]["kernel_ms"],
     "hbm_bytes_per_launch": p["FETCH_SIZE"] * 1024 * 2 + p["WRITE_SIZE"] * 1024,
     "note_fetch": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); equals the "
                   "algorithmic state load chains*coords*4 B",
-    "clock_GHz": cycles / (kern_ms * 1e-3) / 1e9 if kern_ms else None,
+    "note_clock": "GRBM cycles come from the 4-launch PMC run, whose launches are slower (clock still ramping) than the timed ones",
     "valu_insts_per_proposal": p["SQ_INSTS_VALU"] * 64 / props,
     "simd_cycles_per_wave_proposal": cycles * 1024 / (props / 64),
     "VALUBusy_gfx9_formula_pct": 100 * p["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cycles,
