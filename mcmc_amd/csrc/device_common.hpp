@@ -490,6 +490,26 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Whole-wave (G = 64) reductions end with the two gfx9 wavefront-broadcast DPP steps (row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3) and ONE v_readlane_b32 of lane 63 instead of two ds_bpermute_b32 round trips through
+// the LDS queue (~100 cycles of latency each, paid eight times per culled sample and once per pair pass before).  Rows
+// outside the row mask receive `neutral`, so their lanes keep their value; only lane 63 is read.  For commutative
+// operations the value is bit-identical to the butterfly's: (r3 op r2) op (r1 op r0) against (r0 op r1) op (r2 op r3).
+constexpr int DPP_ROW_BCAST15 = 0x142; // lane 15 of each row -> the next row
+constexpr int DPP_ROW_BCAST31 = 0x143; // lane 31 -> rows 2 and 3
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_rows_f32(float neutral, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, neutral), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
+
+__device__ __forceinline__ float lane63_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // Product over the G lanes of an aligned group (G power of two <= 64).
 template <int G>
 __device__ __forceinline__ float group_prod(float v)
@@ -498,9 +518,14 @@ __device__ __forceinline__ float group_prod(float v)
     if constexpr (G >= 4) v *= dpp_f32<DPP_QUAD_XOR2>(v);
     if constexpr (G >= 8) v *= dpp_f32<DPP_ROW_HALF_MIRROR>(v);
     if constexpr (G >= 16) v *= dpp_f32<DPP_ROW_MIRROR>(v);
-    if constexpr (G >= 32) v *= __shfl_xor(v, 16, 64);
-    if constexpr (G >= 64) v *= __shfl_xor(v, 32, 64);
-    return v;
+    if constexpr (G == 64) {
+        v *= dpp_rows_f32<DPP_ROW_BCAST15, 0xA>(1.0f, v);
+        v *= dpp_rows_f32<DPP_ROW_BCAST31, 0xC>(1.0f, v);
+        return lane63_f32(v);
+    } else {
+        if constexpr (G >= 32) v *= __shfl_xor(v, 16, 64);
+        return v;
+    }
 }
 
 // Minimum / maximum over all 64 lanes; every lane receives the result.
@@ -510,22 +535,12 @@ __device__ __forceinline__ float wave_minf(float v)
     v = __builtin_fminf(v, dpp_f32<DPP_QUAD_XOR2>(v));
     v = __builtin_fminf(v, dpp_f32<DPP_ROW_HALF_MIRROR>(v));
     v = __builtin_fminf(v, dpp_f32<DPP_ROW_MIRROR>(v));
-    v = __builtin_fminf(v, __shfl_xor(v, 16, 64));
-    v = __builtin_fminf(v, __shfl_xor(v, 32, 64));
-    return v;
+    v = __builtin_fminf(v, dpp_rows_f32<DPP_ROW_BCAST15, 0xA>(v, v));
+    v = __builtin_fminf(v, dpp_rows_f32<DPP_ROW_BCAST31, 0xC>(v, v));
+    return lane63_f32(v);
 }
 
 __device__ __forceinline__ float wave_maxf(float v) { return -wave_minf(-v); }
-
-// c + (h ? 1 : 0) as ONE VALU op: the compare result stays a lane mask in SGPRs and enters
-// v_addc_co_u32 as the carry (hipcc otherwise materialises 0/1 with v_cndmask and adds).
-__device__ __forceinline__ uint32_t count_if(uint32_t c, bool h)
-{
-    const uint64_t m = __builtin_amdgcn_ballot_w64(h);
-    uint32_t r;
-    asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(r) : "v"(c), "s"(m) : "vcc");
-    return r;
-}
 
 template <int G>
 __device__ __forceinline__ uint32_t group_sum_u32(uint32_t v)
@@ -534,9 +549,14 @@ __device__ __forceinline__ uint32_t group_sum_u32(uint32_t v)
     if constexpr (G >= 4) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_XOR2, 0xF, 0xF, true);
     if constexpr (G >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_HALF_MIRROR, 0xF, 0xF, true);
     if constexpr (G >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_MIRROR, 0xF, 0xF, true);
-    if constexpr (G >= 32) v += (uint32_t)__shfl_xor((int)v, 16, 64);
-    if constexpr (G >= 64) v += (uint32_t)__shfl_xor((int)v, 32, 64);
-    return v;
+    if constexpr (G == 64) {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false);
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    } else {
+        if constexpr (G >= 32) v += (uint32_t)__shfl_xor((int)v, 16, 64);
+        return v;
+    }
 }
 
 } // namespace mcmc

@@ -277,20 +277,48 @@ __device__ __forceinline__ float2 transverse(float r, float u0, float u1)
     return o;
 }
 
+// Black-disk hit test `d2 < hit_d2` as a float 0 / 1 without a condition register: clamp(big * (hit_d2 - d2), 0, 1) in ONE
+// v_fma_f32 with the clamp modifier.  big = 2^k is chosen from hit_d2's exponent so that the smallest positive difference
+// of two floats below hit_d2 (half an ulp of hit_d2) still scales to >= 4: the result is exactly 1.0f for d2 < hit_d2 and
+// exactly 0.0f otherwise (d2 = hit_d2 gives 0; a padded pair at d2 ~ 1e60 overflows to -inf and clamps to 0), i.e. the
+// same decision bit for bit as the comparison.  hipcc's form of `count += (d2 < hit)` is v_cmp into an SGPR pair + v_addc:
+// 16 SGPR pairs live in the unrolled tile made the kernel spill SGPRs; the float counters need none.
+struct HitScale {
+    float neg_big, hit_big;
+};
+
+__device__ __forceinline__ HitScale hit_scale(float hit_d2)
+{
+    HitScale h;
+    const uint32_t e = (__builtin_bit_cast(uint32_t, hit_d2) >> 23) & 0xFFu; // biased exponent
+    float big = 0x1p60f;
+    if (e >= 30u && e <= 250u) big = __builtin_bit_cast(float, (280u - e) << 23); // 2^(26 - (e - 127))
+    h.neg_big = -big;
+    h.hit_big = hit_d2 > 0.0f ? hit_d2 * big : -1.0f; // no hit distance: the indicator is 0 for every d2 >= 0
+    return h;
+}
+
+__device__ __forceinline__ float hit_indicator(float d2, const HitScale &h)
+{
+    float t;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(d2), "s"(h.neg_big), "v"(h.hit_big));
+    return t;
+}
+
 // The A x B pair tile of one lane.  The G lanes of an event form a GA x GB grid: lane (la, lb)
 // owns the A nucleons i = la + GA*k (read from LDS, one ds_read_b64 per JC pairs, prefetched one
 // iteration ahead) and keeps JC of its B nucleons j = lb + GB*(q0+q) in registers.  In FAST math
 // the stored positions are pre-multiplied by sqrt(log2(e)/(2 beta)), so a pair costs
 // 2 sub + mul + fma + v_exp_f32 + fma + mul.
 template <int JC, int MATH, bool PROD, bool HITS>
-__device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, uint32_t *partE, uint32_t nAe, uint32_t nBe,
+__device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, uint8_t *partE, uint32_t nAe, uint32_t nBe,
                                           uint32_t la, uint32_t lb, uint32_t GA, uint32_t GB, uint32_t q0, float &prod,
                                           uint32_t &ncoll)
 {
     // nAe / nBe: the A nucleons trE[0 .. nAe) and B nucleons trE[p.nA .. p.nA + nBe) that take part (all of them,
     // or what sab_cull kept)
     float bx[JC], by[JC], pr[JC];
-    uint32_t cq[JC]; // HITS: collisions of B nucleon q (per-q counters double as the participant flags)
+    float cq[JC]; // HITS: collisions of B nucleon q (per-q counters double as the participant flags); exact integers < 2^24
 #pragma unroll
     for (int q = 0; q < JC; ++q) {
         const uint32_t j = lb + (q0 + q) * GB;
@@ -299,8 +327,9 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
         bx[q] = ok ? v.x : 1.0e30f; // d^2 = inf -> Gamma = 0 -> factor exactly 1, never a hit
         by[q] = ok ? v.y : 0.0f;
         pr[q] = 1.0f;
-        cq[q] = 0u;
+        cq[q] = 0.0f;
     }
+    const HitScale hs = hit_scale(p.hit_d2);
     uint32_t i = la;
     if (i < nAe) {
         float2 a = trE[i];
@@ -322,12 +351,12 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
                     if constexpr (PROD) pr[q] *= 1 - p.G0 * expf(-d2 / p.twoBeta); // IntegrateSAB.cuh:12,75
                 }
                 if constexpr (HITS) {
-                    cq[q] = count_if(cq[q], d2 < p.hit_d2);
+                    cq[q] += hit_indicator(d2, hs);
                     dmin = __builtin_fminf(dmin, d2);
                 }
             }
             if constexpr (HITS) {
-                if (dmin < p.hit_d2) partE[i] = 1u; // benign race: every writer stores 1
+                if (dmin < p.hit_d2) partE[i] = 1; // benign race: every writer stores 1
             }
             if (!more) break;
             a = an;
@@ -338,8 +367,8 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
     for (int q = 0; q < JC; ++q) {
         if constexpr (PROD) prod *= pr[q];
         if constexpr (HITS) {
-            ncoll += cq[q];
-            if (cq[q] != 0u) partE[p.nA + lb + (q0 + q) * GB] = 1u; // a padded j never collides
+            ncoll += (uint32_t)cq[q];
+            if (cq[q] != 0.0f) partE[p.nA + lb + (q0 + q) * GB] = 1; // a padded j never collides
         }
     }
 }
@@ -403,7 +432,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     //   float2  st [EPB][nN]   (x, aux)
     //   float2  trA[EPB][nN]   transverse positions, even sweep of the pair
     //   float2  trB[EPB][nN]   odd sweep
-    //   uint32  part[EPB][nN]  participant marks (HITS only)
+    //   uint8   part[EPB][nN]  participant marks (HITS only)
     TgtLds *tgt = reinterpret_cast<TgtLds *>(smem);
     size_t off = ((sizeof(TgtLds) * nN + 15) / 16) * 16;
     float2 *st = reinterpret_cast<float2 *>(smem + off);
@@ -412,7 +441,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     off += sizeof(float2) * (size_t)EPB * nN;
     float2 *trB = reinterpret_cast<float2 *>(smem + off);
     off += sizeof(float2) * (size_t)EPB * nN;
-    uint32_t *part = reinterpret_cast<uint32_t *>(smem + off);
+    uint8_t *part = reinterpret_cast<uint8_t *>(smem + off);
 
     const int tid = threadIdx.x;
     const int e_local = tid / G;
@@ -439,16 +468,27 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     float2 *stE = st + (size_t)e_local * nN;
     float2 *trAE = trA + (size_t)e_local * nN;
     float2 *trBE = trB + (size_t)e_local * nN;
-    uint32_t *partE = part + (size_t)e_local * nN;
+    uint8_t *partE = part + (size_t)e_local * nN;
     for (uint32_t n = lg; n < nN; n += G) { // CopyLocalMHVars, Metropolis.cuh:61-66
         const float x = p.prevSample[(uint64_t)n * p.T + e];
         stE[n] = make_float2(x, sab_aux_init<KIND, RULE, MATH>(tgt[n], x));
-        if constexpr (HITS) partE[n] = 0u;
+        if constexpr (HITS) partE[n] = 0;
     }
 
     float sum = 0.0f, err = 0.0f;
     uint32_t h_coll = 0, h_inel = 0, h_part = 0;
     const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
+#ifdef MCMC_SAB_PROFILE
+    // Diagnostic build (tools/gpu_sab_phases.sh): shader-clock stamps around the phases of a step pair; the per-event
+    // totals REPLACE the kernel's outputs (hits[0..2] = MH/angle phase, culling + marks, pair sweeps; result = all).
+    uint64_t pc_mh = 0, pc_cull = 0, pc_pair = 0;
+    const uint64_t pc_begin = __builtin_amdgcn_s_memtime();
+#define MCMC_PROF(acc, t0) acc += __builtin_amdgcn_s_memtime() - (t0)
+#define MCMC_PROF_T(name) const uint64_t name = __builtin_amdgcn_s_memtime()
+#else
+#define MCMC_PROF(acc, t0) ((void)0)
+#define MCMC_PROF_T(name) ((void)0)
+#endif
 
     // After the target table above, every LDS word an event touches is private to the event's G lanes, and those lie
     // in ONE wavefront (G divides 64).  A wave's LDS operations execute in program order, so between one lane's
@@ -551,7 +591,10 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         }
         constexpr bool EXIT0 = PROD && !HITS && G == 64; // product only: a zero product ends the event sample
         constexpr bool DROP0 = PROD && HITS && G == 64;  // with hit counters: a zero product ends the exp work only
+        MCMC_PROF_T(pc_c0);
         if (cull_on && (cull_next || !EXIT0)) sab_cull(trE);
+        MCMC_PROF(pc_cull, pc_c0);
+        MCMC_PROF_T(pc_p0);
         const uint32_t JB = (nBe + GB - 1) / GB;
         float prod = 1.0f;
         uint32_t ncoll = 0;
@@ -596,6 +639,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
             h_coll += ncoll;
             h_inel += ncoll > 0 ? 1u : 0u;
         }
+        MCMC_PROF(pc_pair, pc_p0);
     };
 
     // participants of the sweep just done: count and clear the marks
@@ -603,14 +647,14 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         uint32_t c = 0;
         for (uint32_t n = lg; n < nN; n += G) {
             c += partE[n];
-            partE[n] = 0u;
+            partE[n] = 0;
         }
         h_part += group_sum_u32<G>(c);
     };
 
     // Inelastic-only mode, one event per wavefront, Philox draws: the angles of a sample are fresh draws, not
     // chain state, so they are only worked out for the nucleons a sweep actually looks at.  The MH loop leaves
-    // the radii in the position buffers; the probe subset (the first 2 GA nucleons of A, the first 4 GB of B)
+    // the radii in the position buffers; the probe subset (the first 2 GA nucleons of A, the first 4 GB of B, 64 at most)
     // gets its angles (one Philox block per nucleon and step pair + sqrt/sin/cos) at once, the other nucleons
     // only if a probe of this step pair finds no collision.  Counter-based draws: the positions are bit-identical
     // to the eager evaluation, whichever nucleons are skipped.
@@ -625,6 +669,7 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
             const bool actA = te >= ta, actB = te + 1 < tb;
             bool lazy = false, needA = actA, needB = actB; // need*: the sweep is still to be done by pair_sweep
             if constexpr (LAZY) lazy = cull_on && lazy_on;
+            MCMC_PROF_T(pc_m0);
             for (uint32_t n = lg; n < nN; n += G) {
                 float2 s = stE[n];
                 const TgtLds tl = tgt[n];
@@ -682,10 +727,15 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                 stE[n] = s;
             }
             event_sync();
+            MCMC_PROF(pc_mh, pc_m0);
+            MCMC_PROF_T(pc_z0);
             if constexpr (LAZY) {
                 if (lazy) {
-                    const uint32_t nAp = 2u * GA < p.nA ? 2u * GA : p.nA;
-                    const uint32_t nBp = 4u * GB < p.nB ? 4u * GB : p.nB;
+                    // at most 64 nucleons in all, so that their angles are one round of the wave
+                    const uint32_t nAq = 2u * GA < 32u ? 2u * GA : 32u;
+                    const uint32_t nAp = nAq < p.nA ? nAq : p.nA;
+                    const uint32_t nBq = 4u * GB < 64u - nAp ? 4u * GB : 64u - nAp;
+                    const uint32_t nBp = nBq < p.nB ? nBq : p.nB;
                     // radius -> transverse position of nucleon n, both steps of the pair (IntegrateSAB.cuh:50-61)
                     auto angles = [&](uint32_t n) __attribute__((always_inline)) {
                         const u32x4 q = draw_block(p.seed, gid, n, blk, TAG_ANGLE);
@@ -722,16 +772,25 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
                     }
                 }
             }
+            if constexpr (LAZY) MCMC_PROF(pc_cull, pc_z0);
+            MCMC_PROF_T(pc_s0);
             if (needA) pair_sweep(trAE);
+            if constexpr (INEL) MCMC_PROF(pc_pair, pc_s0);
             if constexpr (HITS) {
+                MCMC_PROF_T(pc_k0);
                 event_sync();
                 if (actA) count_marks();
                 event_sync();
+                MCMC_PROF(pc_cull, pc_k0);
             }
+            MCMC_PROF_T(pc_s1);
             if (needB) pair_sweep(trBE);
+            if constexpr (INEL) MCMC_PROF(pc_pair, pc_s1);
             if constexpr (HITS) {
+                MCMC_PROF_T(pc_k1);
                 event_sync();
                 if (actB) count_marks();
+                MCMC_PROF(pc_cull, pc_k1);
             }
             event_sync();
         }
@@ -742,12 +801,26 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     if (valid && lg == 0) {
         if constexpr (PROD) p.result[e] = (sum - err) / p.samples; // IntegrateSAB.cuh:88
         if constexpr (INEL) p.hits[e] = h_inel;
+#ifdef MCMC_SAB_PROFILE
+        if constexpr (INEL) { // one output only: MCMC_SAB_PROFILE = 1 MH phase, 2 lazy angles + probes, 3 pair sweeps, 4 everything
+            const uint64_t pc_all = __builtin_amdgcn_s_memtime() - pc_begin;
+            p.hits[e] = (uint32_t)(MCMC_SAB_PROFILE == 1 ? pc_mh : MCMC_SAB_PROFILE == 2 ? pc_cull : MCMC_SAB_PROFILE == 3 ? pc_pair : pc_all);
+        }
+#endif
         if constexpr (HITS) {
             p.hits[e] = h_coll;
             p.hits[p.T + e] = h_inel;
             p.hits[2 * p.T + e] = h_part;
+#ifdef MCMC_SAB_PROFILE
+            p.hits[e] = (uint32_t)pc_mh;
+            p.hits[p.T + e] = (uint32_t)pc_cull;
+            p.hits[2 * p.T + e] = (uint32_t)pc_pair;
+            if constexpr (PROD) p.result[e] = (float)(__builtin_amdgcn_s_memtime() - pc_begin);
+#endif
         }
     }
+#undef MCMC_PROF
+#undef MCMC_PROF_T
 }
 
 // ---------------------------------------------------------------------

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--rule", default="recip")
     ap.add_argument("--which", default="c3,c4,he")
     ap.add_argument("--bs", default="0,7,14", help="impact parameters (fm) of the Pb-Pb S_AB launches")
+    ap.add_argument("--hits-b", type=float, default=7.0, help="impact parameter (fm) of the product + counters launches")
     ap.add_argument("--inel-bs", default="0,7,14,18", help="impact parameters (fm) of the Pb-Pb inelastic-only launches")
     args = ap.parse_args()
     rule = {"recip": L.ACCEPT_RECIP, "nodiv": L.ACCEPT_NODIV, "cross": L.ACCEPT_CROSS, "log": L.ACCEPT_LOG}[args.rule]
@@ -77,12 +78,12 @@ def main():
             # product + counters at b = 7 fm: bounding boxes cull nothing and the counters forbid the zero-product
             # exit, so with the culling off every nominal pair IS evaluated (evaluated = nominal)
             L.check(L.lib.mcmc_set_option(b"MCMC_SAB_CULL", cull.encode()))
-            ms = timed(lambda: xs.MCIntegrate_S_AB(args.samples, 7.0, stepsize=2.2, dmax2=6.76 / 3.14159265), args.reps)
-            print(json.dumps({"kernel": "MCIntegrate_S_AB+hits", "system": "Pb-208+Pb-208", "b": 7.0, "cull": cull == "1",
+            ms = timed(lambda: xs.MCIntegrate_S_AB(args.samples, args.hits_b, stepsize=2.2, dmax2=6.76 / 3.14159265), args.reps)
+            print(json.dumps({"kernel": "MCIntegrate_S_AB+hits", "system": "Pb-208+Pb-208", "b": args.hits_b, "cull": cull == "1",
                               "events": T, "samples": args.samples, "ms": ms, "event_samples_per_s": n / (ms * 1e-3),
                               "nominal_pairs_per_s": n * 208 * 208 / (ms * 1e-3),
                               "evaluated_pairs_per_s": n * 208 * 208 / (ms * 1e-3) if cull == "0" else None,
-                              "hits": xs.hits.cpu().tolist()}))
+                              "hits": xs.hits.cpu().tolist(), "S_AB": float(xs.sabMean.item())}))
         L.lib.mcmc_set_option(b"MCMC_SAB_CULL", None)
         for b in [float(v) for v in args.inel_bs.split(",")]:
             ms = timed(lambda: xs.MCIntegrate_Inel(args.samples, b, 6.76 / 3.14159265, stepsize=2.2), args.reps)
