@@ -59,6 +59,18 @@ $(LIB7): $(OBJS7)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS7)
 philox7: $(LIB7)
 
+# Diagnostic builds of the S_AB kernel with shader-clock stamps around its phases (tools/gpu_sab_phases*.sh); the
+# libraries go to tools/bin (they travel to the GPU box; delete them after use: 15 MB each)
+PROF = build/prof
+sabprof: $(LIB)
+	mkdir -p $(PROF) tools/bin
+	$(HIPCC) $(HIPFLAGS) -DMCMC_SAB_MODE=3 -DMCMC_SAB_PROFILE=1 -c $(CSRC)/sab_mode.hip -o $(PROF)/sab_mode_3.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o tools/bin/libmcmc_hip_sabprof.so $(filter-out $(OBJ)/sab_mode_3.o,$(OBJS)) $(PROF)/sab_mode_3.o
+	for v in 1 2 3 4; do \
+	  $(HIPCC) $(HIPFLAGS) -DMCMC_SAB_MODE=4 -DMCMC_SAB_PROFILE=$$v -c $(CSRC)/sab_mode.hip -o $(PROF)/sab_mode_4_$$v.o && \
+	  $(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o tools/bin/libprof4_$$v.so $(filter-out $(OBJ)/sab_mode_4.o,$(OBJS)) $(PROF)/sab_mode_4_$$v.o || exit 1; \
+	done
+
 drivers: $(LIB)
 	@if [ -f mcmc_amd/host/stepsize_main.cpp ]; then \
 	  g++ -O3 -std=c++17 -Iinclude -Imcmc_amd/host -o mcmc_amd/host/stepsize mcmc_amd/host/stepsize_main.cpp \
@@ -73,7 +85,7 @@ oracle:
 clean:
 	rm -rf build $(LIB) $(LIB7) mcmc_amd/host/stepsize mcmc_amd/host/xsection
 	$(MAKE) -C oracle clean
-.PHONY: all drivers oracle probes philox7 clean
+.PHONY: sabprof all drivers oracle probes philox7 clean
 
 # device probe of include/mcmc_distributions.h (tests/test_distributions_header.py)
 probes: tools/bin/dist_probe
