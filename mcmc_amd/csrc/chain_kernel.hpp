@@ -62,7 +62,9 @@ template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, bool 
 #ifndef MCMC_LAG_BLOCKS_PER_CU
 #define MCMC_LAG_BLOCKS_PER_CU 3
 #endif
-__global__ __launch_bounds__(CHAIN_BLOCK, NLAG > 0 ? MCMC_LAG_BLOCKS_PER_CU : 1) void chain_kernel(const ChainParams p)
+// FP32 with lags: 3 blocks per CU (168 VGPRs hold the 49 + 57 lag registers).  FP64 with lags keeps 49 double samples and
+// 49 double accumulators beside the float ones: no register cap (one block per CU), or it spills ~700 registers.
+__global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC_LAG_BLOCKS_PER_CU : 1) void chain_kernel(const ChainParams p)
 {
     constexpr int NL = NLAG > 0 ? NLAG : 1;
     __shared__ double sred[CHAIN_WAVES][3 + 3 * NL];
