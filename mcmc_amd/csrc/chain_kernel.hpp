@@ -113,6 +113,13 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
         const uint64_t gid = p.chain_offset + ch;
         Real *state = (Real *)p.state + (uint64_t)coord * nc + ch;
 
+        // this chain's draw stream: the block-independent part of Philox rounds 1-2 (device_common.hpp).  Not with the
+        // lag products: that kernel sits at its register cap and the five words more cost it 10 % (measured).
+        constexpr bool STREAM = NLAG == 0 && !INJ;
+        PhiloxStream pstream = {};
+        if constexpr (STREAM) pstream = philox_stream(p.seed, gid, coord, philox_cw(3 * (t_begin >> 3), TAG_MH));
+        (void)pstream;
+
         Real x = *state;
         Real aux;          // float: 1/p | p | log p | d or g (CROSS); double: p(x)
         float aux2 = 0.0f; // CROSS: n
@@ -252,7 +259,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
                 constexpr int J = decltype(j_tag)::value;
                 Real z0 = 0, z1 = 0, u0 = 0, u1 = 0;
                 if constexpr (!INJ) {
-                    const u32x4 w = pair_words<J>(p.seed, gid, coord, g, sp);
+                    // full groups: the caller has checked that pstream covers the group's blocks
+                    const u32x4 w = (FULL && STREAM) ? pair_words_stream<J>(pstream, p.seed, g, sp) : pair_words<J>(p.seed, gid, coord, g, sp);
                     if constexpr (sizeof(Real) == 4) {
                         float a, b, c, d;
                         pair_draws_f32<MATH, PRESCALED>(w, scale2, a, b, c, d);
@@ -294,7 +302,14 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
             while (g < g_full_end) {
                 uint64_t stop = (g | 15u) + 1; // the float partial sums are folded into FP64 every <= 128 steps
                 if (stop > g_full_end) stop = g_full_end;
-                for (; g < stop; ++g) do_group(std::true_type{}, g, ta, tb);
+                // the stream's precomputed rounds hold while the block index stays below the next multiple of 2^32
+                const uint32_t cw_a = philox_cw(3 * g, TAG_MH), cw_b = philox_cw(3 * stop - 1, TAG_MH);
+                if (!STREAM || cw_a == cw_b) {
+                    if (STREAM && cw_a != pstream.cw) pstream = philox_stream(p.seed, gid, coord, cw_a);
+                    for (; g < stop; ++g) do_group(std::true_type{}, g, ta, tb);
+                } else {
+                    for (; g < stop; ++g) do_group(std::false_type{}, g, ta, tb); // range-tested steps, generic draws
+                }
                 flush();
             }
             if (g < g_end) do_group(std::false_type{}, g, ta, tb);

@@ -137,6 +137,9 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
     const float scale2 = -1.3862943611198906f * p.stepsize * p.stepsize;
     const uint64_t ta = p.step_offset, tb = p.step_offset + p.samples;
     const uint64_t gid = p.event_offset + e;
+    PhiloxStream pstream = {};
+    if constexpr (!INJ) pstream = philox_stream(p.seed, gid, n, philox_cw(3 * (ta >> 3), TAG_MH));
+    (void)pstream;
 
     auto one = [&](uint64_t t, float z, float u) __attribute__((always_inline)) {
         if constexpr (INJ) {
@@ -163,7 +166,8 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
             constexpr int J = decltype(j_tag)::value;
             float z0 = 0, z1 = 0, u0 = 0, u1 = 0;
             if constexpr (!INJ) {
-                const u32x4 w = pair_words<J>(p.seed, gid, n, g, sp);
+                // full groups of the fast loop: the chain's precomputed Philox rounds (device_common.hpp, PhiloxStream)
+                const u32x4 w = FULL ? pair_words_stream<J>(pstream, p.seed, g, sp) : pair_words<J>(p.seed, gid, n, g, sp);
                 pair_draws_f32<MATH, PRESCALED>(w, scale2, z0, z1, u0, u1);
             }
             const uint64_t t0 = (g << 3) + 2 * J;
@@ -182,7 +186,18 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
             do_group(std::false_type{}, g);
             ++g;
         }
-        for (; g < g_full_end; ++g) do_group(std::true_type{}, g);
+        // the stream holds while the block index 3g + j stays below the next multiple of 2^32: in chunks of 2^20 groups
+        while (g < g_full_end) {
+            uint64_t stop = (g | 0xFFFFFu) + 1;
+            if (stop > g_full_end) stop = g_full_end;
+            const uint32_t cw_a = philox_cw(3 * g, TAG_MH), cw_b = philox_cw(3 * stop - 1, TAG_MH);
+            if (cw_a == cw_b) {
+                if (cw_a != pstream.cw) pstream = philox_stream(p.seed, gid, n, cw_a);
+                for (; g < stop; ++g) do_group(std::true_type{}, g);
+            } else {
+                for (; g < stop; ++g) do_group(std::false_type{}, g); // range-tested steps, generic draws
+            }
+        }
         if (g < g_end) do_group(std::false_type{}, g);
     }
     if (valid) {
