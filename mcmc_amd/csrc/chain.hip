@@ -233,7 +233,7 @@ __global__ void draws_kernel(uint64_t seed, uint64_t chain_offset, uint64_t n_ch
     const uint64_t id = chain_offset + c;
     if (normals || uniforms) {
         for (uint64_t g = ta >> 3; g <= ((tb - 1) >> 3); ++g) {
-            uint32_t sp[3];
+            Spare sp = {};
             u32x4 w[4];
             w[0] = pair_words<0>(seed, id, coord, g, sp);
             w[1] = pair_words<1>(seed, id, coord, g, sp);

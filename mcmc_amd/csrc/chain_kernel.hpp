@@ -254,7 +254,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
         // group of a launch) each step is range-tested and shifts the window itself.
         auto do_group = [&](auto full_tag, uint64_t g, uint64_t ta, uint64_t tb) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
-            uint32_t sp[3] = {0u, 0u, 0u};
+            Spare sp = {};
             auto body = [&](auto j_tag) __attribute__((always_inline)) {
                 constexpr int J = decltype(j_tag)::value;
                 Real z0 = 0, z1 = 0, u0 = 0, u1 = 0;

@@ -134,72 +134,92 @@ __device__ __forceinline__ float u01(uint32_t r)
 }
 
 // ---- packed MH draws -------------------------------------------------
-// A group of 8 steps (4 step pairs) costs 3 Philox blocks instead of 4: every word gives a 23-bit
-// field from its TOP 23 bits, and the 4 low bytes of each block form a "spare" word; the fourth
-// pair is made of the three spares.  A field becomes a float in [1,2) with ONE v_alignbit_b32
-// (0x7F : word >> 9 is exponent 0 + 23 mantissa bits).
-__device__ __forceinline__ float mant12(uint32_t w)
+// A group of 8 steps (4 step pairs) costs 3 Philox blocks instead of 4: every word gives a 23-bit field from its LOW
+// 23 bits -- ONE v_bitop3_b32, (w & 0x7FFFFF) | 0x3F800000, turns it into a float in [1,2) (3.1 issue cycles; the
+// v_alignbit_b32 that took the TOP 23 bits before cost 4.1) -- and the top bytes of the 12 words make the four fields of
+// the fourth pair: field j = top bytes of words 0, 1, 2 of block j (24 bits, the low 23 kept), field 3 = top bytes of
+// word 3 of blocks 0, 1, 2.  Two v_perm_b32 + one v_bitop3_b32 per spare field.  pair_words returns the fields of a
+// pair as the bit patterns of those floats.
+__device__ __forceinline__ uint32_t field12(uint32_t w)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_alignbit(0x7Fu, w, 9u));
+    return __builtin_amdgcn_bitop3_b32(w, 0x007FFFFFu, 0x3F800000u, 0xEA); // (a & b) | c
 }
 
-constexpr float MANT_OPEN = 0.99999994f; // 1 - 2^-24: mant12(w) - MANT_OPEN = (2m+1) 2^-24 in (0,1)
+__device__ __forceinline__ float mant12(uint32_t field_bits) { return __builtin_bit_cast(float, field_bits); }
 
-__device__ __forceinline__ uint32_t spare_bytes(const u32x4 &w)
+constexpr float MANT_OPEN = 0.99999994f; // 1 - 2^-24: mant12(f) - MANT_OPEN = (2m+1) 2^-24 in (0,1)
+
+// spare fields of a group, filled block by block; c carries the top bytes of the blocks' fourth words
+struct Spare {
+    uint32_t f[3];
+    uint32_t c;
+};
+
+template <int J>
+__device__ __forceinline__ void spare_take(const u32x4 &w, Spare &sp)
 {
     // v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0c = zero
-    const uint32_t t01 = __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0400u);
-    const uint32_t t23 = __builtin_amdgcn_perm(w.w, w.z, 0x0c0c0400u);
-    return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+    const uint32_t t = __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0703u);       // w0.b3 | w1.b3 << 8
+    sp.f[J] = field12(__builtin_amdgcn_perm(w.z, t, 0x0c070100u));         // ... | w2.b3 << 16
+    if constexpr (J == 0) sp.c = w.w;
+    else if constexpr (J == 1) sp.c = __builtin_amdgcn_perm(w.w, sp.c, 0x0c0c0703u);
+    else sp.c = field12(__builtin_amdgcn_perm(w.w, sp.c, 0x0c070100u));
 }
 
-// the four words of step pair 3 of a group from the spares of its blocks 0..2
-__device__ __forceinline__ u32x4 spare_pair(uint32_t s0, uint32_t s1, uint32_t s2)
+__device__ __forceinline__ u32x4 block_fields(const u32x4 &w)
 {
     u32x4 r;
-    r.x = s0;
-    r.y = s1;
-    r.z = s2;
-    const uint32_t t = __builtin_amdgcn_perm(s1, s0, 0x0c04000cu); // 0 | s0.b0 << 8 | s1.b0 << 16
-    r.w = __builtin_amdgcn_perm(s2, t, 0x04020100u);               // ... | s2.b0 << 24
+    r.x = field12(w.x);
+    r.y = field12(w.y);
+    r.z = field12(w.z);
+    r.w = field12(w.w);
     return r;
 }
 
-// Words of step pair J (0..3) of group g; sp[] carries the spares across J = 0..2 -> 3.
+__device__ __forceinline__ u32x4 spare_fields(const Spare &sp)
+{
+    u32x4 r;
+    r.x = sp.f[0];
+    r.y = sp.f[1];
+    r.z = sp.f[2];
+    r.w = sp.c;
+    return r;
+}
+
+// Fields of step pair J (0..3) of group g; sp carries the spares across J = 0..2 -> 3.
 template <int J>
-__device__ __forceinline__ u32x4 pair_words_tag(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, uint32_t tag,
-                                                uint32_t (&sp)[3])
+__device__ __forceinline__ u32x4 pair_words_tag(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, uint32_t tag, Spare &sp)
 {
     if constexpr (J < 3) {
         const u32x4 w = draw_block(seed, id, coord, 3 * g + J, tag);
-        sp[J] = spare_bytes(w);
-        return w;
+        spare_take<J>(w, sp);
+        return block_fields(w);
     } else {
-        return spare_pair(sp[0], sp[1], sp[2]);
+        return spare_fields(sp);
     }
 }
 
 template <int J>
-__device__ __forceinline__ u32x4 pair_words(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, uint32_t (&sp)[3])
+__device__ __forceinline__ u32x4 pair_words(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, Spare &sp)
 {
     return pair_words_tag<J>(seed, id, coord, g, TAG_MH, sp);
 }
 
-// The same words through a PhiloxStream kept by the caller for the (id, coord, tag) it iterates over.  Precondition
+// The same fields through a PhiloxStream kept by the caller for the (id, coord, tag) it iterates over.  Precondition
 // (the caller tests it outside its hot loop): the group's blocks 3g .. 3g+2 have the counter word st.cw.
 template <int J>
-__device__ __forceinline__ u32x4 pair_words_stream(const PhiloxStream &st, uint64_t seed, uint64_t g, uint32_t (&sp)[3])
+__device__ __forceinline__ u32x4 pair_words_stream(const PhiloxStream &st, uint64_t seed, uint64_t g, Spare &sp)
 {
     if constexpr (J < 3) {
         const u32x4 w = draw_block_stream(st, seed, (uint32_t)(3 * g + J));
-        sp[J] = spare_bytes(w);
-        return w;
+        spare_take<J>(w, sp);
+        return block_fields(w);
     } else {
-        return spare_pair(sp[0], sp[1], sp[2]);
+        return spare_fields(sp);
     }
 }
 
-// Draws of one step pair from its words: normals (z0 even step, z1 odd step) and accept uniforms.
+// Draws of one step pair from its fields: normals (z0 even step, z1 odd step) and accept uniforms.
 //   MATH FAST + SCALED: returns step * z (scale2 = -2 ln2 step^2 folded into the radius)
 template <int MATH, bool SCALED>
 __device__ __forceinline__ void pair_draws_f32(const u32x4 &w, float scale2, float &z0, float &z1, float &u0, float &u1)

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
             for (uint32_t gi = 0; gi < D / 8; ++gi) {
                 const uint64_t g = (n0 >> 3) + gi;
                 const f8 qd8 = p.q_diag[gi], qh8 = p.q_half[gi], qo8 = p.q_off[gi];
-                uint32_t sp[3] = {0u, 0u, 0u};
+                Spare sp = {};
                 auto body = [&](auto j_tag) __attribute__((always_inline)) {
                     constexpr int J = decltype(j_tag)::value;
                     float z[2] = {0.0f, 0.0f}, u[2] = {0.0f, 0.0f};
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p
             auto group = [&](auto gi_tag) __attribute__((always_inline)) {
                 constexpr int GI = decltype(gi_tag)::value;
                 const uint64_t g = (n0 >> 3) + GI;
-                uint32_t sp[3] = {0u, 0u, 0u};
+                Spare sp = {};
                 auto body = [&](auto j_tag) __attribute__((always_inline)) {
                     constexpr int J = decltype(j_tag)::value;
                     float z[2], u[2];

@@ -161,7 +161,7 @@ __device__ __forceinline__ void xs_chain_body(const XsParams &p, const mcmc_targ
     // groups of 8 steps = 4 step pairs from 3 Philox blocks (packed draws, device_common.hpp)
     auto do_group = [&](auto full_tag, uint64_t g) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
-        uint32_t sp[3] = {0u, 0u, 0u};
+        Spare sp = {};
         auto body = [&](auto j_tag) __attribute__((always_inline)) {
             constexpr int J = decltype(j_tag)::value;
             float z0 = 0, z1 = 0, u0 = 0, u1 = 0;

@@ -84,41 +84,40 @@ static float orc_u01_f32(uint32_t r)
     return fmaf((float)r, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
 }
 
-/* Packed MH draws (tag 0).  Steps are grouped by 8 (group g = t >> 3), a group
- * into 4 step pairs j = (t >> 1) & 3.  Blocks B_0..B_2 = Philox(blk = 3 g + j)
- * serve pairs 0..2: each of the 4 words gives a 23-bit field from its TOP 23
- * bits; the 4 low bytes of a block are its "spare" word
- *   S_j = w0.b0 | w1.b0 << 8 | w2.b0 << 16 | w3.b0 << 24.
- * Pair 3 is made of the spares: fields from the top 23 bits of S_0, S_1, S_2
- * and of (S_0.b0 << 8 | S_1.b0 << 16 | S_2.b0 << 24).  So 128 Philox bits
- * carry 5 1/3 draws of 23 bits instead of 4 of 32.
+/* Packed MH draws (tag 0; tag 3 for the stress target).  Steps are grouped by 8
+ * (group g = t >> 3), a group into 4 step pairs j = (t >> 1) & 3.  Blocks
+ * B_0..B_2 = Philox(blk = 3 g + j) serve pairs 0..2: each of the 4 words gives a
+ * 23-bit field from its LOW 23 bits.  The top bytes of the 12 words make the four
+ * fields of pair 3:
+ *   field j (j = 0..2) = low 23 bits of  B_j.w0.b3 | B_j.w1.b3 << 8 | B_j.w2.b3 << 16,
+ *   field 3            = low 23 bits of  B_0.w3.b3 | B_1.w3.b3 << 8 | B_2.w3.b3 << 16.
+ * So 384 Philox bits carry 16 draws of 23 bits instead of 12 of 32.
  * Field m -> uniform (2m + 1) 2^-24 in (0,1) (never 0, never 1); the
  * Box-Muller angle uses the fraction m 2^-23 itself (a grid symmetric under
  * theta -> theta + 1/2, so proposals stay exactly symmetric).
  * Pair fields: m[0] radius, m[1] angle, m[2] / m[3] accept uniform of the
  * even / odd step.                                                         */
-static uint32_t orc_spare(const uint32_t w[4])
+static void orc_group_fields(uint64_t seed, uint64_t id, uint32_t coord, uint64_t g, uint32_t tag, uint32_t m[4][4])
 {
-    return (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8) | ((w[2] & 0xFFu) << 16) | ((w[3] & 0xFFu) << 24);
+    uint32_t w[3][4];
+    for (uint32_t j = 0; j < 3; ++j) {
+        orc_block(seed, id, coord, 3 * g + j, tag, w[j]);
+        for (int k = 0; k < 4; ++k) m[j][k] = w[j][k] & 0x7FFFFFu;
+        m[3][j] = ((w[j][0] >> 24) | ((w[j][1] >> 24) << 8) | ((w[j][2] >> 24) << 16)) & 0x7FFFFFu;
+    }
+    m[3][3] = ((w[0][3] >> 24) | ((w[1][3] >> 24) << 8) | ((w[2][3] >> 24) << 16)) & 0x7FFFFFu;
+}
+
+static void orc_pair_fields_tag(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, uint32_t tag, uint32_t m[4])
+{
+    uint32_t all[4][4];
+    orc_group_fields(seed, id, coord, t >> 3, tag, all);
+    memcpy(m, all[(t >> 1) & 3u], sizeof(uint32_t) * 4);
 }
 
 static void orc_pair_fields(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, uint32_t m[4])
 {
-    uint64_t g = t >> 3;
-    uint32_t j = (uint32_t)(t >> 1) & 3u;
-    uint32_t w[4];
-    if (j < 3) {
-        orc_block(seed, id, coord, 3 * g + j, 0u, w);
-    } else {
-        uint32_t sp[3];
-        for (uint32_t k = 0; k < 3; ++k) {
-            orc_block(seed, id, coord, 3 * g + k, 0u, w);
-            sp[k] = orc_spare(w);
-        }
-        w[0] = sp[0]; w[1] = sp[1]; w[2] = sp[2];
-        w[3] = ((sp[0] & 0xFFu) << 8) | ((sp[1] & 0xFFu) << 16) | ((sp[2] & 0xFFu) << 24);
-    }
-    for (int k = 0; k < 4; ++k) m[k] = w[k] >> 9;
+    orc_pair_fields_tag(seed, id, coord, t, 0u, m);
 }
 
 static float orc_field_uniform(uint32_t m) { return (float)(2 * m + 1) * 5.9604644775390625e-08f; } /* exact */
@@ -654,25 +653,6 @@ ORC_API void orc_cross_sections(const double *b, const double *S, const double *
  * (tag 3, coord field 0, proposal index n = sweep * dim + i takes the place of the step).
  * trace (optional) [sweeps][dim] positions after each sweep; bits (optional) [sweeps][dim];
  * min_margin (optional) = min |log U - delta| over all proposals.                        */
-static void orc_pair_fields_tag(uint64_t seed, uint64_t id, uint32_t coord, uint64_t t, uint32_t tag, uint32_t m[4])
-{
-    uint64_t g = t >> 3;
-    uint32_t j = (uint32_t)(t >> 1) & 3u;
-    uint32_t w[4];
-    if (j < 3) {
-        orc_block(seed, id, coord, 3 * g + j, tag, w);
-    } else {
-        uint32_t sp[3];
-        for (uint32_t k = 0; k < 3; ++k) {
-            orc_block(seed, id, coord, 3 * g + k, tag, w);
-            sp[k] = orc_spare(w);
-        }
-        w[0] = sp[0]; w[1] = sp[1]; w[2] = sp[2];
-        w[3] = ((sp[0] & 0xFFu) << 8) | ((sp[1] & 0xFFu) << 16) | ((sp[2] & 0xFFu) << 24);
-    }
-    for (int k = 0; k < 4; ++k) m[k] = w[k] >> 9;
-}
-
 ORC_API uint64_t orc_mvn_chain(int dim, const float *q_diag, const float *q_off, float *x, float step, uint64_t sweeps,
                                const float *draws, uint64_t seed, uint64_t chain, uint64_t sweep_offset,
                                float *trace, uint8_t *bits, float *min_margin)
@@ -736,19 +716,14 @@ ORC_API uint64_t orc_baseline_chains_f32(uint64_t chain0, uint64_t n_chains, int
             while (t < tb) {
                 /* one group of 8 steps = 3 Philox blocks, generated once (as the kernel does) */
                 uint64_t g = t >> 3;
-                uint32_t w[4][4], sp[3];
-                for (uint32_t k = 0; k < 3; ++k) {
-                    orc_block(seed, c, (uint32_t)d, 3 * g + k, 0u, w[k]);
-                    sp[k] = orc_spare(w[k]);
-                }
-                w[3][0] = sp[0]; w[3][1] = sp[1]; w[3][2] = sp[2];
-                w[3][3] = ((sp[0] & 0xFFu) << 8) | ((sp[1] & 0xFFu) << 16) | ((sp[2] & 0xFFu) << 24);
+                uint32_t m[4][4];
+                orc_group_fields(seed, c, (uint32_t)d, g, 0u, m);
                 for (uint32_t j = 0; j < 4; ++j) {
-                    float u1 = orc_field_uniform(w[j][0] >> 9);
+                    float u1 = orc_field_uniform(m[j][0]);
                     float rad = sqrtf(-2.0f * logf(u1));
-                    float ang = 6.283185307179586f * ((float)(w[j][1] >> 9) * 1.1920928955078125e-07f);
+                    float ang = 6.283185307179586f * ((float)m[j][1] * 1.1920928955078125e-07f);
                     float z[2] = {rad * cosf(ang), rad * sinf(ang)};
-                    float u[2] = {orc_field_uniform(w[j][2] >> 9), orc_field_uniform(w[j][3] >> 9)};
+                    float u[2] = {orc_field_uniform(m[j][2]), orc_field_uniform(m[j][3])};
                     for (uint32_t h = 0; h < 2; ++h) {
                         uint64_t ts = (g << 3) + 2 * j + h;
                         if (ts < t || ts >= tb) continue;

@@ -184,7 +184,9 @@ def test_split_launches_and_chain_partition_are_invariant(dev):
     torch.cuda.synchronize()
     assert torch.equal(a.state, b.state)
     core = 3 + n_lags
-    np.testing.assert_allclose((s1 + s2)[:, :core].cpu().numpy(), sa[:, :core].cpu().numpy(), rtol=1e-5)
+    # the float kernels keep the lag products in FP32 per launch (mcmc_hip.h): 1000 chains x 300 products of |y y'| <= 6
+    # give each sum a rounding scatter of ~1e-3 in absolute terms, whatever its size (high lags nearly cancel)
+    np.testing.assert_allclose((s1 + s2)[:, :core].cpu().numpy(), sa[:, :core].cpu().numpy(), rtol=1e-5, atol=2e-3)
     np.testing.assert_allclose(s1[:, core:core + n_lags].cpu().numpy(), sa[:, core:core + n_lags].cpu().numpy(), rtol=1e-6)
     np.testing.assert_allclose(s2[:, core + n_lags:].cpu().numpy(), sa[:, core + n_lags:].cpu().numpy(), rtol=1e-6)
     # partition
