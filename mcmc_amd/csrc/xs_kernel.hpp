@@ -229,6 +229,14 @@ struct TgtLds {
     int kind;
 };
 
+// sab_kernel's LDS header: the table of distinct densities, the run count and a byte index per nucleon (host + device)
+constexpr int XS_TGT_MAX = 8;
+// (the modes with hit counters are register-bound at 3 waves per SIMD whatever the table costs: they keep one entry per nucleon)
+__host__ __device__ inline size_t xs_sab_header_bytes(size_t nN, bool per_nucleon)
+{
+    return per_nucleon ? ((sizeof(TgtLds) * nN + 15) / 16) * 16 : ((sizeof(TgtLds) * XS_TGT_MAX + 16 + nN + 15) / 16) * 16;
+}
+
 template <int KIND /* -1: per-nucleon kind */, int RULE, int MATH>
 __device__ __forceinline__ void sab_mh(const TgtLds &tl, float &x, float &aux, float step, float z, float u)
 {
@@ -443,13 +451,22 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t nN = p.nA + p.nB;
     // LDS carve-up (all in one array):
-    //   TgtLds  tgt[nN]
-    //   float2  st [EPB][nN]   (x, aux)
-    //   float2  trA[EPB][nN]   transverse positions, even sweep of the pair
-    //   float2  trB[EPB][nN]   odd sweep
-    //   uint8   part[EPB][nN]  participant marks (HITS only)
-    TgtLds *tgt = reinterpret_cast<TgtLds *>(smem);
-    size_t off = ((sizeof(TgtLds) * nN + 15) / 16) * 16;
+    //   TgtLds  tgtU[XS_TGT_MAX]  the distinct densities, in order of first appearance (runs of equal neighbours)
+    //   uint32  nruns (+ pad)     number of runs found
+    //   uint8   tidx[nN]          run index of every nucleon
+    //   float2  st [EPB][nN]      (x, aux)
+    //   float2  trA[EPB][nN]      transverse positions, even sweep of the pair
+    //   float2  trB[EPB][nN]      odd sweep
+    //   uint8   part[EPB][nN]     participant marks (HITS only)
+    // A table entry per NUCLEON (20 B each, 8.3 KB for Pb-Pb) made the block 48.2 KB: three blocks per CU.  Nuclei have a
+    // handful of species (protons / neutrons of A and B), so the table holds the distinct entries and a byte index per
+    // nucleon: 40.5 KB, four blocks = 4 waves per SIMD.  More than XS_TGT_MAX runs: the densities are read from
+    // p.targets in global memory at every use (slow, correct).
+    TgtLds *tgtU = reinterpret_cast<TgtLds *>(smem);
+    uint32_t *nruns = reinterpret_cast<uint32_t *>(smem + sizeof(TgtLds) * XS_TGT_MAX);
+    uint8_t *tidx = smem + sizeof(TgtLds) * XS_TGT_MAX + 16;
+    constexpr bool PER_NUCLEON = HITS; // one table entry per nucleon (see xs_sab_header_bytes)
+    size_t off = xs_sab_header_bytes(nN, PER_NUCLEON);
     float2 *st = reinterpret_cast<float2 *>(smem + off);
     off += sizeof(float2) * (size_t)EPB * nN;
     float2 *trA = reinterpret_cast<float2 *>(smem + off);
@@ -468,25 +485,57 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
     const uint64_t e = valid ? e0 : 0;
     const uint64_t gid = p.event_offset + e;
 
-    for (uint32_t n = tid; n < nN; n += XS_BLOCK) {
-        const mcmc_target mt = p.targets[n];
-        const Target<float> t = make_target<float>(mt);
+    auto target_from_global = [&](uint32_t n) __attribute__((always_inline)) {
+        const Target<float> t = make_target<float>(p.targets[n]);
         TgtLds tl;
         tl.p0 = t.p0;
         tl.p1 = t.p1;
         tl.k1 = t.k1;
         tl.k0 = t.k0;
         tl.kind = t.kind;
-        tgt[n] = tl;
+        return tl;
+    };
+    if constexpr (PER_NUCLEON) {
+        for (uint32_t n = tid; n < nN; n += XS_BLOCK) tgtU[n] = target_from_global(n);
+        __syncthreads();
+    } else {
+        // every nucleon's density once into scratch (the state / position arrays, not yet in use: 20 B <= 24 EPB B per
+        // nucleon), then wave 0 numbers the runs of equal neighbours: ballot + prefix count, 64 nucleons a round
+        TgtLds *tmp = reinterpret_cast<TgtLds *>(st);
+        for (uint32_t n = tid; n < nN; n += XS_BLOCK) tmp[n] = target_from_global(n);
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t running = 0;
+            for (uint32_t base = 0; base < nN; base += 64) {
+                const uint32_t n = base + (uint32_t)tid;
+                const bool ok = n < nN;
+                const TgtLds a = tmp[ok ? n : 0];
+                const TgtLds b = tmp[ok && n > 0 ? n - 1 : 0];
+                const bool start = ok && (n == 0 || __builtin_bit_cast(uint32_t, a.p0) != __builtin_bit_cast(uint32_t, b.p0) ||
+                                          __builtin_bit_cast(uint32_t, a.p1) != __builtin_bit_cast(uint32_t, b.p1) || a.kind != b.kind);
+                const uint64_t m = __builtin_amdgcn_ballot_w64(start);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t idx = running + below + (start ? 1u : 0u) - 1u; // run of nucleon n (n = 0 starts run 0)
+                if (ok) tidx[n] = (uint8_t)(idx < 255u ? idx : 255u);
+                if (start && idx < (uint32_t)XS_TGT_MAX) tgtU[idx] = a;
+                running += (uint32_t)__builtin_popcountll(m);
+            }
+            if (tid == 0) *nruns = running;
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    const bool tgt_table = PER_NUCLEON || *nruns <= (uint32_t)XS_TGT_MAX; // block-uniform
+    auto target_of = [&](uint32_t n) __attribute__((always_inline)) {
+        if constexpr (PER_NUCLEON) return tgtU[n];
+        else return tgt_table ? tgtU[tidx[n]] : target_from_global(n);
+    };
     float2 *stE = st + (size_t)e_local * nN;
     float2 *trAE = trA + (size_t)e_local * nN;
     float2 *trBE = trB + (size_t)e_local * nN;
     uint8_t *partE = part + (size_t)e_local * nN;
     for (uint32_t n = lg; n < nN; n += G) { // CopyLocalMHVars, Metropolis.cuh:61-66
         const float x = p.prevSample[(uint64_t)n * p.T + e];
-        stE[n] = make_float2(x, sab_aux_init<KIND, RULE, MATH>(tgt[n], x));
+        stE[n] = make_float2(x, sab_aux_init<KIND, RULE, MATH>(target_of(n), x));
         if constexpr (HITS) partE[n] = 0;
     }
 
@@ -685,9 +734,18 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
             bool lazy = false, needA = actA, needB = actB; // need*: the sweep is still to be done by pair_sweep
             if constexpr (LAZY) lazy = cull_on && lazy_on;
             MCMC_PROF_T(pc_m0);
+            // the table index of the NEXT nucleon is fetched one iteration ahead (tidx -> tgtU is a dependent LDS read)
+            uint32_t ti = (!PER_NUCLEON && tgt_table && (uint32_t)lg < nN) ? tidx[lg] : 0u;
             for (uint32_t n = lg; n < nN; n += G) {
                 float2 s = stE[n];
-                const TgtLds tl = tgt[n];
+                TgtLds tl;
+                if constexpr (PER_NUCLEON) {
+                    tl = tgtU[n];
+                } else {
+                    const uint32_t ti_next = (tgt_table && n + G < nN) ? tidx[n + G] : 0u;
+                    tl = tgt_table ? tgtU[ti] : target_from_global(n);
+                    ti = ti_next;
+                }
                 float z0 = 0, z1 = 0, u0 = 0, u1 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
                 if constexpr (!INJ) {
                     const u32x4 r = draw_block(p.seed, gid, n, blk, TAG_SAB_MH);

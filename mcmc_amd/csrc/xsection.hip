@@ -161,7 +161,7 @@ size_t sab_lds_bytes(int G, uint32_t nA, uint32_t nB, bool hits)
     const size_t nN = (size_t)nA + nB;
     const size_t epb = XS_BLOCK / G;
     // participant marks are bytes: with uint32 marks four Pb-Pb events took 54.9 KB and only two blocks fitted a CU
-    return align_up(sizeof(TgtLds) * nN, 16) + 3 * sizeof(float2) * epb * nN + (hits ? align_up(epb * nN, 16) : 0);
+    return xs_sab_header_bytes(nN, hits) + 3 * sizeof(float2) * epb * nN + (hits ? align_up(epb * nN, 16) : 0);
 }
 
 SabPlan sab_plan(uint32_t nA, uint32_t nB, bool hits, const SabOptions &opt)

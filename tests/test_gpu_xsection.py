@@ -137,6 +137,43 @@ def test_sab_injected(dev, oracle, mode, nA, nB, b):
         assert abs(hits[2] - tot[2]) <= max(2, 1e-4 * tot[2])
 
 
+@pytest.mark.parametrize("layout", ["species", "alternating", "all_distinct"])
+def test_sab_per_nucleon_densities(dev, oracle, layout):
+    """pdfArr (main.cu:47-51) is one density per nucleon.  The S_AB kernel keeps the DISTINCT densities in LDS with a byte
+    index per nucleon: 4 runs (protons / neutrons of A and B), 12 alternating runs and 14 distinct ones (more runs than
+    table entries: the kernel reads the densities from global memory) all have to reproduce the oracle."""
+    nA, nB = 6, 8
+    nN = nA + nB
+    if layout == "species":
+        targets = [(O.R2WS, 2.0, 0.54)] * 3 + [(O.R2WS, 2.2, 0.5)] * 3 + [(O.R2WS, 2.54, 0.5)] * 4 + [(O.R2WS, 2.4, 0.6)] * 4
+    elif layout == "alternating":
+        targets = [(O.R2WS, 2.0, 0.54) if n % 2 == 0 or n >= 12 else (O.R2WS, 2.54, 0.5) for n in range(nN)]
+    else:
+        targets = [(O.R2WS, 2.0 + 0.05 * n, 0.5 + 0.01 * n) for n in range(nN)]
+    T, samples, step, b = 41, 11, 2.2, 1.0
+    rng = np.random.default_rng(5)
+    d = np.empty((T, samples * nN * 4), dtype=np.float32)
+    blk = d.reshape(T, samples, 2, nN, 2)
+    blk[:, :, 0, :, 0] = rng.standard_normal((T, samples, nN))
+    blk[:, :, 0, :, 1] = 1.0 - rng.random((T, samples, nN))
+    blk[:, :, 1, :, :] = 1.0 - rng.random((T, samples, nN, 2))
+    xs = _xs(dev, nA, nB, T, targets, "recip_fast")
+    res, mean, _ = xs.MCIntegrate_S_AB(samples, b, stepsize=step, injected=torch.from_numpy(d).to(dev))
+    torch.cuda.synchronize()
+    res, st = res.cpu().numpy(), xs.prevSample.cpu().numpy()
+    strict = 0
+    for e in range(T):
+        mh = d[e].reshape(samples, 2, nN, 2)[:, 0].reshape(samples, nN * 2)
+        _, _, _, margin = oracle.warmup_thread_trace(targets, [1.0] * nN, step, samples, mh)
+        x, m, _, _ = oracle.integrate_sab_thread(nA, nB, targets, [1.0] * nN, step, samples, b, d[e])
+        if margin <= _tie("recip_fast"):
+            continue
+        strict += 1
+        np.testing.assert_allclose(st[:, e], x, rtol=1e-6)
+        assert res[e] == pytest.approx(m, rel=2e-4, abs=1e-7), (e, res[e], m)
+    assert strict >= np.floor(T * 0.85), (strict, T)
+
+
 def test_sab_philox_matches_oracle_on_device_draws(dev, oracle):
     """Philox mode == injected mode fed with the library's own draws (He-4 + He-4, main.cu:38-41)."""
     from mcmc_amd import lib as L
