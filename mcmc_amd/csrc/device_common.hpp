@@ -382,7 +382,7 @@ __device__ __forceinline__ float pdf_eval(const Target<float> &t, float r)
 //   CROSS : the density is kept as a quotient and the test p' >= U p is cross-multiplied, so no
 //           reciprocal is evaluated at all:
 //             WS      p = 1/d        aux = d = 1 + e^((r-c)/a)         d >= U d'
-//             R2WS    p = n/d        aux = d, aux2 = n = r^2           n' d >= (U n) d'
+//             R2WS    p = n/(1+e)    aux = e, aux2 = n = r^2           n' (1 + e) >= (U n) (1 + e')
 //             GAUSS   p = 2^g        aux = g = -r^2 log2e/(2v)         2^(g'-g) >= U
 //             R2GAUSS p = n 2^g      aux = g, aux2 = n = r^2           n' 2^(g'-g) >= U n
 template <int KIND, int RULE, int MATH>
@@ -401,8 +401,8 @@ __device__ __forceinline__ void mh_aux_init(const Target<float> &t, float x, flo
         const float inf = __builtin_inff();
         const float rp = __builtin_fmaxf(x, 0.0f);
         if constexpr (KIND == MCMC_TARGET_WS || KIND == MCMC_TARGET_R2WS) {
-            const float d = 1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(x, t.k1, t.k0));
-            aux = (KIND == MCMC_TARGET_WS && x < 0.0f) ? inf : d;
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(x, t.k1, t.k0));
+            aux = KIND == MCMC_TARGET_R2WS ? e : (x < 0.0f ? inf : 1.0f + e);
             aux2 = rp * rp;
         } else {
             const float g = x * x * t.k1;
@@ -514,11 +514,13 @@ __device__ __forceinline__ uint64_t mh_step_dz(const Target<float> &t, float &x,
             dn = next < 0.0f ? inf : dn;       // p' = 0: inf on the right-hand side rejects
             return select2_ge(aux, uniform * dn, aux, dn, x, next);
         } else if constexpr (KIND == MCMC_TARGET_R2WS) {
-            const float dn = 1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(next, t.k1, t.k0));
+            // aux = e = d - 1: n' d >= (U n) d' as n' e + n' >= (U n) e' + (U n), two FMAs and no `1 + e'`
+            const float en = __builtin_amdgcn_exp2f(__builtin_fmaf(next, t.k1, t.k0));
             // n' = r |r| (the |.| is a source modifier): r^2 for r >= 0; for r < 0 a negative left-hand side,
             // which fails against the non-negative right-hand side as n' = 0 would -- no v_max_f32 (4 cycles)
             const float nn = next * __builtin_fabsf(next);
-            return select3_ge(nn * aux, (uniform * aux2) * dn, aux, dn, aux2, nn, x, next);
+            const float un = uniform * aux2;
+            return select3_ge(__builtin_fmaf(nn, aux, nn), __builtin_fmaf(un, en, un), aux, en, aux2, nn, x, next);
         } else if constexpr (KIND == MCMC_TARGET_GAUSS) {
             float gn = next * next * t.k1;
             gn = next < 0.0f ? -inf : gn;
