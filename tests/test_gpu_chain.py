@@ -116,6 +116,26 @@ def test_philox_draws_match_oracle(dev, oracle):
                 assert abs(sz[i, c] - szn) <= tol * max(1.0, abs(szn))
 
 
+@pytest.mark.parametrize("t0", [0, 40, (2 ** 32 // 3) * 8 - 72])
+def test_precomputed_philox_rounds_equal_the_generic_blocks(dev, t0):
+    """Full groups of the FAST kernels draw through a PhiloxStream (rounds 1-2 worked out once per chain); one-step
+    launches are partial groups and take the generic block.  Same trajectory bit for bit -- also where the block index
+    3 g + j crosses 2^32 (the stream's counter word changes: t0 = 11453246048, crossing 72 steps later)."""
+    from mcmc_amd import lib as L
+    kw = dict(n_chains=300, n_coords=2, target=R2WS_REF, step=2.48, precision=32, accept_rule=L.ACCEPT_CROSS,
+              math_mode=L.MATH_FAST, seed=99)
+    a, b = _engine(dev, **kw), _engine(dev, **kw)
+    a.steps_done = b.steps_done = t0
+    n = 160
+    a.run(n)
+    for _ in range(n):
+        b.run(1)
+    torch.cuda.synchronize()
+    assert a.steps_done == b.steps_done == t0 + n
+    assert torch.equal(a.state, b.state)
+    assert not torch.equal(a.state, torch.ones_like(a.state))
+
+
 def test_philox_mode_trajectory_matches_oracle_on_device_draws(dev, oracle):
     """Philox mode == injected mode fed with the library's own draws (logic parity at any seed)."""
     from mcmc_amd import lib as L
