@@ -224,7 +224,9 @@ typedef struct {
     int32_t accept_rule;        /* MCMC_ACCEPT_RECIP, _NODIV, _LOG (FAST math) or _CROSS.  CROSS keeps the density as a
                                    quotient (two cached values per chain): the warm-up and R2 kernels run it as such;
                                    the S_AB / inelastic kernels hold ONE cached value per nucleon in LDS and evaluate
-                                   CROSS as NODIV -- the same decision p' >= U p, identical away from exact ties */
+                                   CROSS as NODIV -- the same decision p' >= U p, identical away from exact ties (for
+                                   r^2 Woods-Saxon in FAST math NODIV itself is evaluated cross-multiplied there, with
+                                   e^((r-c)/a) cached and r^2 recomputed: no reciprocal) */
     int32_t math_mode;
     int32_t uniform_kind;       /* -1: kinds differ per nucleon (read from `targets` on the device);
                                    otherwise every nucleon has this mcmc_target_kind, which selects a

@@ -237,6 +237,26 @@ __host__ __device__ inline size_t xs_sab_header_bytes(size_t nN, bool per_nucleo
     return per_nucleon ? ((sizeof(TgtLds) * nN + 15) / 16) * 16 : ((sizeof(TgtLds) * XS_TGT_MAX + 16 + nN + 15) / 16) * 16;
 }
 
+// NODIV for r^2 Woods-Saxon inside the S_AB kernels, FAST math: the test p' >= U p in the cross-multiplied form of the
+// chain kernels' CROSS rule, with ONE cached value per nucleon (the LDS state is (x, aux)): aux = e = exp((r - c)/a),
+// n = r |r| recomputed from r.  n' (1 + e) >= (U n)(1 + e') as two FMAs -- no reciprocal, no `1 + e'`, no v_max:
+// 12 VALU instructions (37 issue cycles) instead of 14 (50).  A start at r < 0 (density 0) carries e = +inf: every
+// proposal onto r' > 0 is accepted and none onto r' <= 0, as `p' * (1 / 0) >= U` does in the reference (Metropolis.cuh:47).
+template <int MATH>
+__device__ __forceinline__ constexpr bool sab_cross_form(int kind, int rule)
+{
+    return MATH == MCMC_MATH_FAST && rule == MCMC_ACCEPT_NODIV && kind == MCMC_TARGET_R2WS;
+}
+
+__device__ __forceinline__ void sab_mh_r2ws_cross(const Target<float> &t, float &x, float &e, float step, float z, float u)
+{
+    const float next = x + step * z; // Metropolis.cuh:43: mul + add
+    const float en = __builtin_amdgcn_exp2f(__builtin_fmaf(next, t.k1, t.k0));
+    const float nn = next * __builtin_fabsf(next);
+    const float un = u * (x * __builtin_fabsf(x));
+    select2_ge(__builtin_fmaf(nn, e, nn), __builtin_fmaf(un, en, un), e, en, x, next);
+}
+
 template <int KIND /* -1: per-nucleon kind */, int RULE, int MATH>
 __device__ __forceinline__ void sab_mh(const TgtLds &tl, float &x, float &aux, float step, float z, float u)
 {
@@ -247,11 +267,15 @@ __device__ __forceinline__ void sab_mh(const TgtLds &tl, float &x, float &aux, f
     tg.k1 = tl.k1;
     tg.k0 = tl.k0;
     if constexpr (KIND >= 0) {
-        mh_step<KIND, RULE, MATH>(tg, x, aux, step, z, u);
+        if constexpr (sab_cross_form<MATH>(KIND, RULE)) sab_mh_r2ws_cross(tg, x, aux, step, z, u);
+        else mh_step<KIND, RULE, MATH>(tg, x, aux, step, z, u);
     } else {
         switch (tl.kind) {
         case MCMC_TARGET_WS: mh_step<MCMC_TARGET_WS, RULE, MATH>(tg, x, aux, step, z, u); break;
-        case MCMC_TARGET_R2WS: mh_step<MCMC_TARGET_R2WS, RULE, MATH>(tg, x, aux, step, z, u); break;
+        case MCMC_TARGET_R2WS:
+            if constexpr (sab_cross_form<MATH>(MCMC_TARGET_R2WS, RULE)) sab_mh_r2ws_cross(tg, x, aux, step, z, u);
+            else mh_step<MCMC_TARGET_R2WS, RULE, MATH>(tg, x, aux, step, z, u);
+            break;
         case MCMC_TARGET_GAUSS: mh_step<MCMC_TARGET_GAUSS, RULE, MATH>(tg, x, aux, step, z, u); break;
         default: mh_step<MCMC_TARGET_R2GAUSS, RULE, MATH>(tg, x, aux, step, z, u); break;
         }
@@ -267,12 +291,18 @@ __device__ __forceinline__ float sab_aux_init(const TgtLds &tl, float x)
     tg.p1 = tl.p1;
     tg.k1 = tl.k1;
     tg.k0 = tl.k0;
+    auto cross_e = [&]() __attribute__((always_inline)) {
+        return x < 0.0f ? __builtin_inff() : __builtin_amdgcn_exp2f(__builtin_fmaf(x, tg.k1, tg.k0));
+    };
     if constexpr (KIND >= 0) {
-        return mh_aux_init<KIND, RULE, MATH>(tg, x);
+        if constexpr (sab_cross_form<MATH>(KIND, RULE)) return cross_e();
+        else return mh_aux_init<KIND, RULE, MATH>(tg, x);
     } else {
         switch (tl.kind) {
         case MCMC_TARGET_WS: return mh_aux_init<MCMC_TARGET_WS, RULE, MATH>(tg, x);
-        case MCMC_TARGET_R2WS: return mh_aux_init<MCMC_TARGET_R2WS, RULE, MATH>(tg, x);
+        case MCMC_TARGET_R2WS:
+            if constexpr (sab_cross_form<MATH>(MCMC_TARGET_R2WS, RULE)) return cross_e();
+            else return mh_aux_init<MCMC_TARGET_R2WS, RULE, MATH>(tg, x);
         case MCMC_TARGET_GAUSS: return mh_aux_init<MCMC_TARGET_GAUSS, RULE, MATH>(tg, x);
         default: return mh_aux_init<MCMC_TARGET_R2GAUSS, RULE, MATH>(tg, x);
         }
