@@ -17,7 +17,8 @@ namespace {
 // Register-resident kernel: the stress configuration's own shape only
 bool mvn_reg_applies(const mcmc_mvn_args *a)
 {
-    if (a->dim != MVN_REG_DIM || a->observable != 0 || a->inj || a->samples_full || a->accept_bits) return false;
+    if (a->dim != MVN_REG_DIM || a->observable != 0 || a->inj || a->accept_bits) return false;
+    if (a->samples_full && a->n_chains >= (1ull << 30)) return false; // its stores address a row with a 32-bit lane offset
     static const int env = [] {
         const char *v = std::getenv("MCMC_MVN_REG");
         return v && v[0] == '0' ? 0 : v && v[0] == '1' ? 1 : -1;
@@ -107,8 +108,14 @@ extern "C" int mcmc_mvn_run(const mcmc_mvn_args *a, void *stream)
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(mvn_grid(a->n_chains)), block(MVN_BLOCK);
     if (mvn_reg_applies(a)) {
-        if (a->math_mode == MCMC_MATH_FAST) hipLaunchKernelGGL(mvn_reg_kernel<MCMC_MATH_FAST>, grid, block, 0, s, p);
-        else hipLaunchKernelGGL(mvn_reg_kernel<MCMC_MATH_PRECISE>, grid, block, 0, s, p);
+        const bool full = a->samples_full != nullptr;
+        if (a->math_mode == MCMC_MATH_FAST) {
+            if (full) hipLaunchKernelGGL((mvn_reg_kernel<MCMC_MATH_FAST, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((mvn_reg_kernel<MCMC_MATH_FAST, false>), grid, block, 0, s, p);
+        } else {
+            if (full) hipLaunchKernelGGL((mvn_reg_kernel<MCMC_MATH_PRECISE, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((mvn_reg_kernel<MCMC_MATH_PRECISE, false>), grid, block, 0, s, p);
+        }
         MCMC_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(mvn_finalize_kernel, dim3(MVN_STATS), dim3(256), 0, s, (const double *)a->workspace, a->stats,
                            (int)grid.x);

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
 
 // ---------------------------------------------------------------------
 // Register-resident twin of mvn_kernel for the stress configuration itself (D = 64, observable = coordinate 0,
-// Philox draws, no full-state / accept-flag write-back): the chain's 64 coordinates live in VGPRs, the sweep is
+// Philox draws, no accept-flag write-back): the chain's 64 coordinates live in VGPRs, the sweep is
 // unrolled over them (static register indices), nothing goes through LDS.  LDS capacity (256 B per chain) holds the
 // LDS kernel at two waves per SIMD, where its serial dependence x_{i-1} -> x_i is not hidden (rocprofv3: 63-78 % VALU
 // issue occupancy, no LDS stall, profiles/r2_valu_busy_calibrated.json); this kernel is compiled for four.
@@ -203,7 +203,10 @@ __global__ __launch_bounds__(MVN_BLOCK) void mvn_kernel(const MvnParams p)
 // (tests/test_gpu_mvn.py compares the two).
 constexpr int MVN_REG_DIM = 64;
 
-template <int MATH>
+// FULL: every sweep's 64 coordinates go to samples_full[sweep][coord][chain] (the HBM-heavy variant of the stress
+// configuration): streaming stores with a scalar row base and a 32-bit lane offset, issued group by group as the
+// coordinates become final, so the sweep's VALU work covers them.
+template <int MATH, bool FULL>
 __global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p)
 {
     __shared__ double sred[MVN_BLOCK / 64][MVN_STATS];
@@ -241,9 +244,14 @@ __global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p
         uint64_t wacc = 0;
 
         uint32_t row = p.ring_row0;
+        const uint32_t ch32 = (uint32_t)ch; // FULL: n_chains < 2^30 (mvn_reg_applies), so the byte offset fits 32 bits
+        (void)ch32;
 #pragma unroll 1
         for (uint64_t t = ta; t < tb; ++t) {
             const uint64_t n0 = t * D;
+            float *full_row = nullptr; // wave-uniform: samples_full[t - ta][0][0]
+            if constexpr (FULL) full_row = p.samples_full + (t - ta) * (uint64_t)D * nc;
+            (void)full_row;
             auto group = [&](auto gi_tag) __attribute__((always_inline)) {
                 constexpr int GI = decltype(gi_tag)::value;
                 const uint64_t g = (n0 >> 3) + GI;
@@ -278,6 +286,14 @@ __global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p
                 body(std::integral_constant<int, 1>{});
                 body(std::integral_constant<int, 2>{});
                 body(std::integral_constant<int, 3>{});
+                if constexpr (FULL) {
+                    // these eight coordinates are final for this sweep (the next group only reads the last of them)
+                    if (valid) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            __builtin_nontemporal_store(xr[GI * 8 + k], full_row + (uint64_t)(GI * 8 + k) * nc + ch32);
+                    }
+                }
                 // the draws do not depend on the state, so the scheduler would hoist all 24 Philox blocks of a sweep
                 // to its top (243 VGPRs): keep each group of 8 proposals to itself
                 __builtin_amdgcn_sched_barrier(0);

@@ -191,8 +191,12 @@ def test_mvn_register_kernel_equals_lds_kernel(dev, mode):
             obs = torch.empty((40, N), dtype=torch.float32, device=dev)
             s1 = eng.run(13, window=w, samples_obs=obs[:13]).clone()
             s2 = eng.run(27, window=w, samples_obs=obs[13:]).clone()
+            # and with every sweep's full state written back (the register kernel's FULL variant)
+            full = torch.full((9, dim, N), 7.0, dtype=torch.float32, device=dev)
+            s3 = eng.run(9, window=(eng.steps_done, eng.steps_done + 9), samples_full=full).clone()
             torch.cuda.synchronize()
-            out.append((eng.state.clone(), eng.ring.clone(), obs.clone(), s1, s2))
+            assert torch.equal(full[-1], eng.state)
+            out.append((eng.state.clone(), eng.ring.clone(), obs.clone(), s1, s2, full.clone(), s3))
     finally:
         L.lib.mcmc_set_option(b"MCMC_MVN_REG", None)
     for a, b in zip(out[0], out[1]):

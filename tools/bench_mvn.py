@@ -35,6 +35,7 @@ def main():
                 ("mvn_kernel", "0", "full-state SoA write-back + lag ring", dict(samples_obs=obs, samples_full=full), 12 + 4 * D)]
     if D == 64:   # the register-resident kernel exists for the stress configuration's own shape only
         variants.insert(0, ("mvn_reg_kernel", "1", "observable write-back + lag ring", dict(samples_obs=obs), 12))
+        variants.insert(2, ("mvn_reg_kernel", "1", "full-state SoA write-back + lag ring", dict(samples_obs=obs, samples_full=full), 12 + 4 * D))
     for kernel, reg, name, kw, bytes_per in variants:
         L.check(L.lib.mcmc_set_option(b"MCMC_MVN_REG", reg.encode()))
         eng.run(K, window=big, **kw)
