@@ -55,10 +55,13 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 
 // Real = float : Metropolis.cuh:40-52 arithmetic (rules RECIP / NODIV / LOG / CROSS)
 // Real = double: metropolis.hpp:35-47 arithmetic (rule SHORTCIRCUIT)
-// STORE: sample / accept-flag write-back requested (keeps the address arithmetic out of the hot loop otherwise)
+// STORE: 0 = no write-back; 1 = sample and / or accept-flag write-back (which of the two is tested at run time);
+//        2 = samples only, FP32 FAST-math Philox kernels without lags (the throughput case of the write-back path):
+//            no run-time tests in the step, the row (step, coordinate) addressed by a wave-uniform base + the lane's
+//            32-bit byte offset
 // STAMP: diagnostic instantiation (mcmc_chain_clock_probe) -- the same body with one s_memtime / s_memrealtime pair
 //        around the block's tile loop, written to a buffer of their own; no production launch executes a stamp
-template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, bool STORE, bool STAMP = false>
+template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, int STORE, bool STAMP = false>
 #ifndef MCMC_LAG_BLOCKS_PER_CU
 #define MCMC_LAG_BLOCKS_PER_CU 3
 #endif
@@ -112,6 +115,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
         const uint64_t ch = valid ? chain : nc - 1;
         const uint64_t gid = p.chain_offset + ch;
         Real *state = (Real *)p.state + (uint64_t)coord * nc + ch;
+        const uint32_t lane_off_b = (uint32_t)ch * (uint32_t)sizeof(Real); // STORE == 2: n_chains < 2^30 (launch_chain)
+        (void)lane_off_b;
 
         // this chain's draw stream: the block-independent part of Philox rounds 1-2 (device_common.hpp).  Not with the
         // lag products: that kernel sits at its register cap and the five words more cost it 10 % (measured).
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
         auto one_step = [&](auto slot_tag, uint64_t t, Real normal, Real uniform) __attribute__((always_inline)) {
             constexpr int SLOT = decltype(slot_tag)::value;
             uint64_t slot = 0;
-            if constexpr (INJ || STORE) slot = ((t - t_begin) * p.n_coords + coord) * nc + ch;
+            if constexpr (INJ || STORE == 1) slot = ((t - t_begin) * p.n_coords + coord) * nc + ch;
             if constexpr (INJ) {
                 normal = ((const Real *)p.inj_normals)[slot];
                 if constexpr (RULE != MCMC_ACCEPT_SHORTCIRCUIT) uniform = ((const Real *)p.inj_uniforms)[slot];
@@ -226,7 +231,11 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
                     MCMC_LAGH(BASE - 1) = (float)y;
                 }
             }
-            if constexpr (STORE) {
+            if constexpr (STORE == 2) {
+                char *rowp = reinterpret_cast<char *>((Real *)p.samples + ((t - t_begin) * p.n_coords + coord) * nc); // uniform
+                __builtin_nontemporal_store(x, reinterpret_cast<Real *>(rowp + (uint64_t)lane_off_b));
+            }
+            if constexpr (STORE == 1) {
                 // written once, never re-read by this kernel: streaming (nt) stores keep them out of L2's way
                 if (p.samples != nullptr) __builtin_nontemporal_store(x, (Real *)p.samples + slot);
                 if (p.accept_bits != nullptr)
@@ -423,17 +432,23 @@ static __global__ __launch_bounds__(256) void chain_finalize_kernel(const double
 template <int KIND, int RULE, int NLAG>
 void launch_chain_stamped(const ChainParams &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((chain_kernel<float, KIND, RULE, MCMC_MATH_FAST, NLAG, false, false, true>), grid, dim3(CHAIN_BLOCK), 0,
+    hipLaunchKernelGGL((chain_kernel<float, KIND, RULE, MCMC_MATH_FAST, NLAG, false, 0, true>), grid, dim3(CHAIN_BLOCK), 0,
                        s, p);
 }
 
 template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ>
 void launch_chain(const ChainParams &p, dim3 grid, hipStream_t s)
 {
+    if constexpr (sizeof(Real) == 4 && MATH == MCMC_MATH_FAST && NLAG == 0 && !INJ) {
+        if (p.samples != nullptr && p.accept_bits == nullptr && p.n_chains < (1ull << 30)) {
+            hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, 2>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+            return;
+        }
+    }
     if (p.samples != nullptr || p.accept_bits != nullptr)
-        hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, true>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+        hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, 1>), grid, dim3(CHAIN_BLOCK), 0, s, p);
     else
-        hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, false>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+        hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, 0>), grid, dim3(CHAIN_BLOCK), 0, s, p);
 }
 
 } // namespace mcmc

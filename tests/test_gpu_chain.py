@@ -136,6 +136,26 @@ def test_precomputed_philox_rounds_equal_the_generic_blocks(dev, t0):
     assert not torch.equal(a.state, torch.ones_like(a.state))
 
 
+def test_samples_only_writeback_kernel_equals_the_general_one(dev):
+    """FAST-math Philox launches that write samples but no accept flags take an instantiation of their own (no run-time
+    tests in the step, row base + 32-bit lane offset): same samples, states and statistics as the general write-back
+    kernel, for a ragged chain count over many tiles and a launch that starts mid-way through a draw group."""
+    from mcmc_amd import lib as L
+    N, n = 2048 * 256 + 300 + 77, 21
+    kw = dict(n_chains=N, n_coords=2, target=R2WS_REF, step=2.48, precision=32, accept_rule=L.ACCEPT_CROSS,
+              math_mode=L.MATH_FAST, seed=5, center=2.3)
+    a, b = _engine(dev, **kw), _engine(dev, **kw)
+    a.run(3), b.run(3)
+    sa = torch.full((n, 2, N), -1.0, dtype=torch.float32, device=dev)
+    sb = torch.full((n, 2, N), -2.0, dtype=torch.float32, device=dev)
+    bits = torch.zeros((n, 2, N), dtype=torch.uint8, device=dev)
+    ta = a.run(n, samples=sa).clone()
+    tb = b.run(n, samples=sb, accept_bits=bits).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(sa, sb) and torch.equal(a.state, b.state) and torch.equal(ta, tb)
+    assert torch.equal(sa[-1], a.state)
+
+
 def test_philox_mode_trajectory_matches_oracle_on_device_draws(dev, oracle):
     """Philox mode == injected mode fed with the library's own draws (logic parity at any seed)."""
     from mcmc_amd import lib as L

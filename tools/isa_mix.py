@@ -20,7 +20,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NLAG = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 # float, R2WS, CROSS, FAST, NLAG lags, Philox draws, no write-back, no stamps
-KERNEL = f"_ZN4mcmc12chain_kernelIfLi1ELi4ELi1ELi{NLAG}ELb0ELb0ELb0EEEvNS_11ChainParamsE"
+KERNEL = f"_ZN4mcmc12chain_kernelIfLi1ELi4ELi1ELi{NLAG}ELb0ELi0ELb0EEEvNS_11ChainParamsE"
 QUARTER = re.compile(r"^v_(exp_f32|log_f32|rcp_f32|rsq_f32|sqrt_f32|sin_f32|cos_f32)")
 HALF = re.compile(r"^v_(mad_u64_u32|mul_hi_u32|mul_lo_u32|alignbit_b32|perm_b32|bfi_b32|xad_u32|add3_u32|max_f32|min_f32|cmp_|cmpx_)")
 # v_cndmask_b32_e32 (mask in VCC): 7.7 cycles in the v_cmp + 3 v_cndmask pattern (tools/ubench_cal.hip, profiles/r2_ubench_cal.txt)
