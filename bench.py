@@ -547,14 +547,16 @@ def main(argv=None):
         torch.cuda.synchronize()
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ea.record()
-        e2.run(1024, window_start=True, n_lags=L.MAX_LAGS)
+        lag_sweeps = 4096   # the launch length of a step-size study (C2: 10^4); a launch has ~60 steps' worth of fixed cost
+        e2.run(lag_sweeps, window_start=True, n_lags=L.MAX_LAGS)
         eb.record()
         torch.cuda.synchronize()
         tau = e2.summary()[0]["tau_int"]
         if out is not None:
             out["ess_per_sec"] = value / tau
             out["tau_int"] = tau
-            out["lag49_proposals_per_sec_per_gpu"] = sub * args.coords * 1024 / (ea.elapsed_time(eb) * 1e-3)
+            out["lag49_proposals_per_sec_per_gpu"] = sub * args.coords * lag_sweeps / (ea.elapsed_time(eb) * 1e-3)
+            out["lag49_sweeps_per_launch"] = lag_sweeps
     if rank == 0 and n_gpus == 1 and args.workload == "chain" and not args.no_secondary:
         out["secondary"] = secondary(dev)
         p7 = philox7_rate(args)

@@ -574,16 +574,33 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;    // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
 constexpr int DPP_ROW_MIRROR = 0x140;
 
-// Sum over all 64 lanes; every lane receives the total.
+constexpr int DPP_ROW_BCAST15 = 0x142; // lane 15 of each row -> the next row (gfx9 wavefront broadcast)
+constexpr int DPP_ROW_BCAST31 = 0x143; // lane 31 -> rows 2 and 3
+
+// v from the broadcasting lane in the rows of ROW_MASK, +0.0 elsewhere
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_rows_f64(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
+// Sum over all 64 lanes; every lane receives the total.  The two cross-row steps are the wavefront-broadcast DPP
+// controls + a v_readlane_b32 pair of lane 63 instead of two ds_bpermute_b32 round trips per half (the 49-lag kernel
+// does 147 of these per tile).  (r3 + r2) + (r1 + r0): the same bits as the butterfly's (r0 + r1) + (r2 + r3).
 __device__ __forceinline__ double wave_sum(double v)
 {
     v += dpp_f64<DPP_QUAD_XOR1>(v);
     v += dpp_f64<DPP_QUAD_XOR2>(v);
     v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
     v += dpp_f64<DPP_ROW_MIRROR>(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    v += dpp_rows_f64<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_rows_f64<DPP_ROW_BCAST31, 0xC>(v);
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
 }
 
 // Whole-wave (G = 64) reductions end with the two gfx9 wavefront-broadcast DPP steps (row_bcast:15 into rows 1 and 3,
@@ -591,9 +608,6 @@ __device__ __forceinline__ double wave_sum(double v)
 // the LDS queue (~100 cycles of latency each, paid eight times per culled sample and once per pair pass before).  Rows
 // outside the row mask receive `neutral`, so their lanes keep their value; only lane 63 is read.  For commutative
 // operations the value is bit-identical to the butterfly's: (r3 op r2) op (r1 op r0) against (r0 op r1) op (r2 op r3).
-constexpr int DPP_ROW_BCAST15 = 0x142; // lane 15 of each row -> the next row
-constexpr int DPP_ROW_BCAST31 = 0x143; // lane 31 -> rows 2 and 3
-
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_rows_f32(float neutral, float v)
 {
