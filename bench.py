@@ -153,6 +153,7 @@ def secondary(dev):
         n, D, K = 1 << 21, 64, 32
         qd, qo = api.ar1_precision(D, 0.9)
         mv = api.MvnEngine(n, qd, qo, 0.8, 1000, math_mode=L.MATH_FAST, x0=0.0, device=dev)
+        mv.run(1024, window=(0, 1 << 40))   # fill the lag ring, so that the timed launches read it
         obs = torch.empty((K, n), dtype=torch.float32, device=dev)
         t = timed(lambda: mv.run(K, window=(0, 1 << 40), samples_obs=obs))
         out["stress64_lag1000_proposals_per_s"] = n * D * K / t
@@ -361,6 +362,10 @@ class StressWorkload:
         self.eng = api.MvnEngine(args.chains, qd, qo, args.step_size, self.lag, math_mode=L.MATH_FAST, seed=314159265, x0=0.0,
                                  chain_offset=rank * args.chains, device=dev)
         self.obs = torch.empty((args.sweeps, args.chains), dtype=torch.float32, device=dev)
+        # fill the lag ring first: a sweep reads its ring slot only from the window's sweep `lag` on, and the timed
+        # launches are to carry all 12 B per chain-sweep (observable write, ring read, ring write)
+        self.eng.run(self.lag + 24, window=(0, 1 << 40))
+        torch.cuda.synchronize()
         self.proposals_per_launch = args.chains * self.D * args.sweeps
         self.flop_per_proposal = FLOP_MVN_PROPOSAL
         # 12 B per chain-sweep (observable write, ring read, ring write) + state load/store per launch
@@ -483,10 +488,21 @@ def main(argv=None):
                             "transcendentals are not counted as flops, so frac understates VALU occupancy: valu_issue sets "
                             "the issue cycles of the loop's instruction mix against the cycles measured with the shader clock "
                             "of THIS run (DESIGN.md 4.1; counter calibration: profiles/r2_valu_busy_calibrated.json)")
-        elif args.workload == "nucleon":
+        if args.workload in ("nucleon", "stress"):
+            # HBM bytes per launch of this workload's kernel from its committed PMC passes (not measured in this run)
+            prof = {"nucleon": "r2_pmc_nucleon_kernel.json", "stress": "r2_pmc_stress_kernel.json"}[args.workload]
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                if pm["derived"].get("algorithmic_bytes_per_launch") == wl.algorithmic_bytes:   # same shape as profiled
+                    roof["traffic"] = pm["derived"]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = (f"profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                              "workload, tools/gpu_profile.sh; not measured in this run)")
+            except (OSError, KeyError, ValueError):
+                pass
+        if args.workload == "nucleon":
             roof["note"] = ("FP32 VALU-issue-bound like the chain kernel; 24 + 6 (Kahan r^2) algorithmic flop per proposal. "
                             "kernel_ms brackets xs_chain_kernel + the two row-mean kernels of the launch")
-        else:
+        elif args.workload == "stress":
             roof["note"] = ("BASELINE configs[4] calls this the HBM-bound path; measured it is VALU-issue-bound: 64 proposals "
                             "per 12 B of HBM traffic per chain-sweep. `hbm` gives the algorithmic bytes (12 B per chain-sweep + "
                             "state load/store) against 8 TB/s; bound and frac are the VALU figures (22 flop per single-"

@@ -235,8 +235,15 @@ __global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p
         const uint64_t ch = valid ? chain : 0;
         const uint64_t gid = p.chain_offset + ch;
         float xr[D];
+        // eight rows at a time.  (With the row addresses shared between these loads and the stores at the end of the
+        // tile the kernel spilled ~126 registers to scratch around the sweep loop: 508 B per chain, +1.5 GB of HBM
+        // traffic per launch at the stress shape -- rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/r2_pmc_stress_kernel.json)
 #pragma unroll
-        for (int j = 0; j < D; ++j) xr[j] = p.state[(uint64_t)j * nc + ch];
+        for (int j0 = 0; j0 < D; j0 += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xr[j0 + k] = p.state[(uint64_t)(j0 + k) * nc + ch];
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         double S1 = 0, S2 = 0, PL = 0, HEAD = 0, TAIL = 0;
         float s1 = 0, s2 = 0, pl = 0, hd = 0, tl = 0;
@@ -319,8 +326,16 @@ __global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p
         }
         S1 += (double)s1, S2 += (double)s2, PL += (double)pl, HEAD += (double)hd, TAIL += (double)tl;
         if (valid) {
+            // the row addresses are formed again here: reusing the 64 of the loads above keeps 128 VGPRs alive across
+            // the sweep loop, i.e. in scratch (the empty asm hides `ch` from common-subexpression elimination)
+            uint64_t ch_again = ch;
+            asm volatile("" : "+v"(ch_again));
 #pragma unroll
-            for (int j = 0; j < D; ++j) p.state[(uint64_t)j * nc + ch] = xr[j];
+            for (int j0 = 0; j0 < D; j0 += 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p.state[(uint64_t)(j0 + k) * nc + ch_again] = xr[j0 + k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         const double r0 = wave_sum(valid ? S1 : 0.0), r1 = wave_sum(valid ? S2 : 0.0), r3 = wave_sum(valid ? PL : 0.0),
                      r4 = wave_sum(valid ? HEAD : 0.0), r5 = wave_sum(valid ? TAIL : 0.0);

@@ -31,6 +31,7 @@ def main():
     obs = torch.empty((K, n), dtype=torch.float32, device=dev)
     full = torch.empty((K, D, n), dtype=torch.float32, device=dev)
     big = (0, 1 << 40)
+    eng.run(args.lag + 24, window=big)   # fill the lag ring: its slots are read from the window's sweep `lag` on
     variants = [("mvn_kernel", "0", "observable write-back + lag ring", dict(samples_obs=obs), 12),
                 ("mvn_kernel", "0", "full-state SoA write-back + lag ring", dict(samples_obs=obs, samples_full=full), 12 + 4 * D)]
     if D == 64:   # the register-resident kernel exists for the stress configuration's own shape only
