@@ -98,6 +98,9 @@ def main():
                               "SQ_LDS_BANK_CONFLICT_over_SQ_LDS_IDX_ACTIVE": C.get("SQ_LDS_BANK_CONFLICT", 0) / max(C.get("SQ_LDS_IDX_ACTIVE", 1), 1),
                               "SQ_WAIT_INST_LDS_over_SQ_WAVE_CYCLES": C.get("SQ_WAIT_INST_LDS", 0) / max(C.get("SQ_WAVE_CYCLES", 1), 1),
                               "SQ_ACTIVE_INST_LDS_over_SQ_WAVE_CYCLES": C.get("SQ_ACTIVE_INST_LDS", 0) / max(C.get("SQ_WAVE_CYCLES", 1), 1)}
+            if tag == "stress":
+                ent["note"] = ("averages run over every dispatch of tools/bench_mvn.py, the ring-priming launch of 1024 sweeps included: "
+                               "the per-instruction ratios hold, kernel_ms_kernel_trace is NOT the time of a 256-sweep launch (profiles/r2_mvn_stress_v3.jsonl has that)")
             out["kernels"][f"{tag}: {k}"] = ent
 
     # chain kernels: price `other` by the static hot-loop mix (tools/isa_mix.py) instead of the low/high bracket
