@@ -116,7 +116,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
         const uint64_t gid = p.chain_offset + ch;
         Real *state = (Real *)p.state + (uint64_t)coord * nc + ch;
         const uint32_t lane_off_b = (uint32_t)ch * (uint32_t)sizeof(Real); // STORE == 2: n_chains < 2^30 (launch_chain)
-        (void)lane_off_b;
+        const uint32_t row_bytes = (uint32_t)nc * (uint32_t)sizeof(Real);  // one row samples[t][coord][0 .. nc)
+        (void)lane_off_b, (void)row_bytes;
 
         // this chain's draw stream: the block-independent part of Philox rounds 1-2 (device_common.hpp).  Not with the
         // lag products: that kernel sits at its register cap and the five words more cost it 10 % (measured).
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
                 }
             }
             if constexpr (STORE == 2) {
-                char *rowp = reinterpret_cast<char *>((Real *)p.samples + ((t - t_begin) * p.n_coords + coord) * nc); // uniform
-                __builtin_nontemporal_store(x, reinterpret_cast<Real *>(rowp + (uint64_t)lane_off_b));
+                const Real *rowp = (const Real *)p.samples + ((t - t_begin) * p.n_coords + coord) * nc; // uniform
+                store_row_f32(reinterpret_cast<const float *>(rowp), row_bytes, lane_off_b, (float)x);
             }
             if constexpr (STORE == 1) {
                 // written once, never re-read by this kernel: streaming (nt) stores keep them out of L2's way

@@ -551,6 +551,19 @@ __device__ __forceinline__ uint64_t mh_step(const Target<float> &t, float &x, fl
 }
 
 // ---------------------------------------------------------------------
+// Sample write-back: one float per lane into a row out[0 .. row_bytes/4) whose base is wave-uniform.  A buffer
+// store takes the 48-bit row base from SGPRs (the descriptor is rebuilt per row by the scalar unit) and a 32-bit
+// byte offset from one VGPR that never changes, so a store is ONE vector-memory instruction with no VALU address
+// arithmetic (a global_store needs a 64-bit VGPR address: v_lshl_add_u64 per store, and two registers kept per row in
+// flight).  Streaming (nt) like the stores it replaces; lanes with lane_off_b >= row_bytes are dropped by the unit's
+// range check.  0x00020000: DATA_FORMAT = 32 (the gfx9 raw-buffer word 3).
+__device__ __forceinline__ void store_row_f32(const float *row, uint32_t row_bytes, uint32_t lane_off_b, float v)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, (int)row_bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)lane_off_b, 0, 2 /* nt */);
+}
+
+// ---------------------------------------------------------------------
 // Wavefront (64 lanes) reductions with DPP row operations, then the two
 // cross-row steps through the permute network; block reductions through LDS.
 template <int CTRL>

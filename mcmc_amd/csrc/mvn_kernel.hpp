@@ -251,8 +251,10 @@ __global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p
         uint64_t wacc = 0;
 
         uint32_t row = p.ring_row0;
-        const uint32_t ch32 = (uint32_t)ch; // FULL: n_chains < 2^30 (mvn_reg_applies), so the byte offset fits 32 bits
-        (void)ch32;
+        // FULL: n_chains < 2^30 (mvn_reg_applies), so a row samples_full[t][i][0 .. nc) and the lane's offset in it fit 32 bits
+        // lanes past the last chain get an offset beyond the row: the buffer unit's range check drops their stores
+        const uint32_t lane_off_b = valid ? (uint32_t)ch * 4u : 0xFFFFFFFCu, row_bytes = (uint32_t)nc * 4u;
+        (void)lane_off_b, (void)row_bytes;
 #pragma unroll 1
         for (uint64_t t = ta; t < tb; ++t) {
             const uint64_t n0 = t * D;
@@ -287,20 +289,16 @@ __global__ __launch_bounds__(MVN_BLOCK, 4) void mvn_reg_kernel(const MvnParams p
                         const bool take = lu <= delta;
                         xr[i] = take ? xc + dz : xc;
                         wacc += (uint64_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(take) & vmask);
+                        // coordinate i is final for this sweep (proposal i + 1 only reads it): one unmasked store per
+                        // proposal instead of eight under `if (valid)` at the end of a group (0.75 -> 0.79 T proposals/s;
+                        // counters of both forms: profiles/r2_store_path_pmc.json)
+                        if constexpr (FULL) store_row_f32(full_row + (uint64_t)i * nc, row_bytes, lane_off_b, xr[i]);
                     }
                 };
                 body(std::integral_constant<int, 0>{});
                 body(std::integral_constant<int, 1>{});
                 body(std::integral_constant<int, 2>{});
                 body(std::integral_constant<int, 3>{});
-                if constexpr (FULL) {
-                    // these eight coordinates are final for this sweep (the next group only reads the last of them)
-                    if (valid) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            __builtin_nontemporal_store(xr[GI * 8 + k], full_row + (uint64_t)(GI * 8 + k) * nc + ch32);
-                    }
-                }
                 // the draws do not depend on the state, so the scheduler would hoist all 24 Philox blocks of a sweep
                 // to its top (243 VGPRs): keep each group of 8 proposals to itself
                 __builtin_amdgcn_sched_barrier(0);
