@@ -128,3 +128,26 @@ def test_mvn_zero_sweep_launch_is_a_no_op(dev):
     torch.cuda.synchronize()
     assert torch.equal(a.state, b.state) and torch.equal(a.ring, b.ring)
     assert torch.equal(sa, sb)
+
+
+def test_chain_writeback_rows_longer_than_2_gib(dev):
+    """Samples-only write-back (buffer stores: the row length is the descriptor's 32-bit NUM_RECORDS, the lane offset a
+    32-bit byte count): a row of 2^29 + 305 chains is 2 GiB + 1220 B, past the signed 32-bit range.  First, middle
+    (around the 2 GiB byte offset) and last chains equal small re-runs of the same global ids; the last row is the state."""
+    from mcmc_amd import lib as L
+    N, n_steps = (1 << 29) + 305, 2
+    kw = dict(n_coords=1, target=R2WS_REF, step=2.48, precision=32, accept_rule=L.ACCEPT_CROSS, math_mode=L.MATH_FAST,
+              n_lags=0, center=2.3, seed=3)
+    a = _chain(dev, n_chains=N, **kw)
+    smp = torch.full((n_steps, 1, N), -5.0, dtype=torch.float32, device=dev)
+    a.run(n_steps, samples=smp)
+    torch.cuda.synchronize()
+    assert torch.equal(a.state, smp[-1])
+    for off in (0, (1 << 29) - 35, N - 70):
+        h = _chain(dev, n_chains=70, chain_offset=off, **kw)
+        smp_h = torch.empty((n_steps, 1, 70), dtype=torch.float32, device=dev)
+        h.run(n_steps, samples=smp_h)
+        torch.cuda.synchronize()
+        assert torch.equal(smp[:, :, off:off + 70], smp_h), off
+    del smp, a
+    torch.cuda.empty_cache()
