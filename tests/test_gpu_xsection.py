@@ -84,13 +84,14 @@ def test_warmup_and_r2_injected(dev, oracle, mode, nN):
         np.testing.assert_allclose(st2[:, e], x2, rtol=1e-6)
         np.testing.assert_allclose(res[:, e], out, rtol=2e-6)
     # (40 + 64) sweeps x nN proposals per event: a tie within the margin is met by < 2 % of the events
+    print(f"strict/total = {strict}/{T}")
     assert strict >= (T - 1 if mode == "recip_precise" else T * 0.9), (strict, T)
     # device run mean (replaces host Average, main.cu:221-223) vs the oracle's FP32 Kahan average
     for n in range(nN):
         assert run_mean[n] == pytest.approx(oracle.average_f32(res[n]), rel=1e-6)
 
 
-@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "log_fast"])
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast", "cross_fast", "log_fast"])
 @pytest.mark.parametrize("nA,nB", [(2, 2), (4, 4), (3, 5), (12, 12), (16, 20), (70, 70), (208, 208), (197, 63)])
 @pytest.mark.parametrize("b", [0.0, 1.5, 5.0])   # 5.0: nuclei that only graze -- the pair culling of G = 64 is active
 def test_sab_injected(dev, oracle, mode, nA, nB, b):
@@ -127,6 +128,7 @@ def test_sab_injected(dev, oracle, mode, nA, nB, b):
         tol = 2e-5 if mode == "recip_precise" else 2e-4
         assert res[e] == pytest.approx(m, rel=tol, abs=1e-7), (e, res[e], m)
     # samples x nN proposals per event (<= 2500 for Pb-Pb): <= 5 % of the events meet a tie within the FAST margin
+    print(f"strict/total = {strict}/{T}")
     assert strict >= (T - 1 if mode == "recip_precise" else np.floor(T * 0.85)), (strict, T)
     assert mean[0] == pytest.approx(res.astype(np.float64).mean(), rel=1e-12)
     assert hits[3] == T * samples
@@ -137,8 +139,9 @@ def test_sab_injected(dev, oracle, mode, nA, nB, b):
         assert abs(hits[2] - tot[2]) <= max(2, 1e-4 * tot[2])
 
 
+@pytest.mark.parametrize("mode", ["recip_fast", "nodiv_fast", "cross_fast"])
 @pytest.mark.parametrize("layout", ["species", "alternating", "all_distinct"])
-def test_sab_per_nucleon_densities(dev, oracle, layout):
+def test_sab_per_nucleon_densities(dev, oracle, layout, mode):
     """pdfArr (main.cu:47-51) is one density per nucleon.  The S_AB kernel keeps the DISTINCT densities in LDS with a byte
     index per nucleon: 4 runs (protons / neutrons of A and B), 12 alternating runs and 14 distinct ones (more runs than
     table entries: the kernel reads the densities from global memory) all have to reproduce the oracle."""
@@ -157,7 +160,7 @@ def test_sab_per_nucleon_densities(dev, oracle, layout):
     blk[:, :, 0, :, 0] = rng.standard_normal((T, samples, nN))
     blk[:, :, 0, :, 1] = 1.0 - rng.random((T, samples, nN))
     blk[:, :, 1, :, :] = 1.0 - rng.random((T, samples, nN, 2))
-    xs = _xs(dev, nA, nB, T, targets, "recip_fast")
+    xs = _xs(dev, nA, nB, T, targets, mode)
     res, mean, _ = xs.MCIntegrate_S_AB(samples, b, stepsize=step, injected=torch.from_numpy(d).to(dev))
     torch.cuda.synchronize()
     res, st = res.cpu().numpy(), xs.prevSample.cpu().numpy()
@@ -166,12 +169,69 @@ def test_sab_per_nucleon_densities(dev, oracle, layout):
         mh = d[e].reshape(samples, 2, nN, 2)[:, 0].reshape(samples, nN * 2)
         _, _, _, margin = oracle.warmup_thread_trace(targets, [1.0] * nN, step, samples, mh)
         x, m, _, _ = oracle.integrate_sab_thread(nA, nB, targets, [1.0] * nN, step, samples, b, d[e])
-        if margin <= _tie("recip_fast"):
+        if margin <= _tie(mode):
             continue
         strict += 1
         np.testing.assert_allclose(st[:, e], x, rtol=1e-6)
         assert res[e] == pytest.approx(m, rel=2e-4, abs=1e-7), (e, res[e], m)
+    print(f"strict/total = {strict}/{T}")
     assert strict >= np.floor(T * 0.85), (strict, T)
+
+
+@pytest.mark.parametrize("mode", ["recip_fast", "nodiv_fast", "cross_fast", "log_fast"])
+@pytest.mark.parametrize("kinds", ["r2ws", "mixed"])
+@pytest.mark.parametrize("nA,nB", [(6, 8), (70, 70)])
+def test_sab_negative_start_and_mixed_kinds(dev, oracle, mode, kinds, nA, nB):
+    """Metropolis.cuh:47-50,64 at its corners: (i) chains started at r < 0, where the r^2 densities are 0 and
+    CopyLocalMHVars caches 1/0 = inf (every proposal onto p' > 0 is accepted, none onto p' = 0: 0 * inf >= U is false);
+    the NODIV / CROSS step of the S_AB kernels carries e = +inf there (sab_aux_init); (ii) per-nucleon target kinds
+    (uniform_kind = -1: the run-time switch inside sab_mh) under every rule.  Chain states, per-event S_AB and the
+    inelastic flag against the oracle's reference rule."""
+    nN = nA + nB
+    T = 33 if nN < 60 else 9
+    samples, step, b = (15 if nN < 60 else 6), 2.2, 1.5
+    if kinds == "r2ws":
+        targets = [WS20 if n % 3 else (O.R2WS, 2.54, 0.5) for n in range(nN)]
+    else:
+        cyc = [(O.R2WS, 2.0, 0.54), (O.WS, 2.0, 0.54), (O.R2GAUSS, 1.3, 0.0), (O.GAUSS, 1.1, 0.0)]
+        targets = [cyc[n % 4] for n in range(nN)]
+    # every other nucleon starts at r < 0 (and nucleon 0 always does); the rest at the reference's 1.0 (main.cu:132)
+    x0 = np.array([(-0.4 - 0.3 * (n % 5)) if n % 2 == 0 else 1.0 for n in range(nN)], dtype=np.float32)
+    rng = np.random.default_rng(nA * 7 + nB + (1 if kinds == "mixed" else 0))
+    d = np.empty((T, samples * nN * 4), dtype=np.float32)
+    blk = d.reshape(T, samples, 2, nN, 2)
+    blk[:, :, 0, :, 0] = rng.standard_normal((T, samples, nN))
+    blk[:, :, 0, :, 1] = 1.0 - rng.random((T, samples, nN))
+    blk[:, :, 1, :, :] = 1.0 - rng.random((T, samples, nN, 2))
+    dmax2 = 4.3 / np.pi
+    dj = torch.from_numpy(d).to(dev)
+    start = torch.from_numpy(np.repeat(x0[:, None], T, axis=1).copy()).to(dev)
+    xs = _xs(dev, nA, nB, T, targets, mode)
+    xs.prevSample.copy_(start)
+    res, _, hits = xs.MCIntegrate_S_AB(samples, b, stepsize=step, injected=dj, dmax2=dmax2)
+    flag = _xs(dev, nA, nB, T, targets, mode)
+    flag.prevSample.copy_(start)
+    inel = flag.MCIntegrate_Inel(samples, b, dmax2, stepsize=step, injected=dj).clone()
+    torch.cuda.synchronize()
+    res, hits, inel, st = res.cpu().numpy(), hits.cpu().numpy(), inel.cpu().numpy(), xs.prevSample.cpu().numpy()
+    assert torch.equal(xs.prevSample, flag.prevSample)
+    assert inel[0] == hits[1] and inel[1] == T * samples
+    strict, tot, all_ok = 0, 0, True
+    for e in range(T):
+        mh = d[e].reshape(samples, 2, nN, 2)[:, 0].reshape(samples, nN * 2)
+        _, bits, _, margin = oracle.warmup_thread_trace(targets, x0, step, samples, mh)
+        x, m, h, _ = oracle.integrate_sab_thread(nA, nB, targets, x0, step, samples, b, d[e], dmax2=dmax2)
+        tot += h[1]
+        if margin <= _tie(mode):
+            all_ok = False
+            continue
+        strict += 1
+        np.testing.assert_allclose(st[:, e], x, rtol=1e-6)
+        assert res[e] == pytest.approx(m, rel=2e-4, abs=1e-7), (e, res[e], m)
+    print(f"strict/total = {strict}/{T}")
+    assert strict >= np.floor(T * 0.85), (strict, T)
+    if all_ok:
+        assert abs(int(inel[0]) - int(tot)) <= 1
 
 
 def test_sab_philox_matches_oracle_on_device_draws(dev, oracle):
@@ -256,8 +316,8 @@ def test_layer_b_sab_scan_and_cross_sections(dev):
         L.check(L.lib.mcmc_destroy(h))
 
 
-@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast"])
-@pytest.mark.parametrize("nA,nB", [(2, 2), (3, 5), (16, 20), (70, 70)])
+@pytest.mark.parametrize("mode", ["recip_precise", "recip_fast", "nodiv_fast", "cross_fast", "log_fast"])
+@pytest.mark.parametrize("nA,nB", [(2, 2), (3, 5), (16, 20), (70, 70), (208, 208)])
 @pytest.mark.parametrize("b", [0.0, 3.0, 5.0])
 def test_inel_injected(dev, oracle, mode, nA, nB, b):
     """Inelastic-flag-only kernel (mcmc_launch_integrate_inel): the count of samples with >= 1 black-disk
