@@ -10,7 +10,7 @@ LIB = mcmc_amd/libmcmc_hip.so
 
 OBJS = $(OBJ)/chain.o $(OBJ)/chain_kind_0.o $(OBJ)/chain_kind_1.o $(OBJ)/chain_kind_2.o $(OBJ)/chain_kind_3.o \
        $(OBJ)/xsection.o $(OBJ)/sab_mode_1.o $(OBJ)/sab_mode_2.o $(OBJ)/sab_mode_3.o $(OBJ)/sab_mode_4.o \
-       $(OBJ)/mvn.o $(OBJ)/capi.o $(OBJ)/errors.o
+       $(OBJ)/mvn.o $(OBJ)/capi.o $(OBJ)/multi.o $(OBJ)/errors.o
 HDRS = $(wildcard $(CSRC)/*.hpp) include/mcmc_hip.h
 
 all: $(LIB) drivers oracle probes
@@ -37,7 +37,7 @@ $(OBJ)/%.o: $(CSRC)/%.cpp $(HDRS) | $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl -lpthread
 
 # The same library with Philox4x32-7 (MCMC_PHILOX_ROUNDS=7): an optional performance build, not part of `all`
 OBJ7 = build/obj7
@@ -56,7 +56,7 @@ $(OBJ7)/%.o: $(CSRC)/%.hip $(HDRS) | $(OBJ7)
 $(OBJ7)/%.o: $(CSRC)/%.cpp $(HDRS) | $(OBJ7)
 	$(HIPCC) $(HIPFLAGS) -DMCMC_PHILOX_ROUNDS=7 -c $< -o $@
 $(LIB7): $(OBJS7)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS7)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS7) -ldl -lpthread
 philox7: $(LIB7)
 
 # Diagnostic builds of the S_AB kernel with shader-clock stamps around its phases (tools/gpu_sab_phases*.sh); the

@@ -294,6 +294,18 @@ int mcmc_launch_row_mean_f32(const float *x, uint32_t rows, uint64_t cols, doubl
                              size_t workspace_bytes, void *stream);
 size_t mcmc_row_mean_workspace_bytes(uint32_t rows, uint64_t cols);
 
+/* Sharding-invariant sum of each row of a [rows][cols] float matrix -- the device side of the multi-GPU form of the
+ * host Average of main.cu:221-223,359 (no other counterpart in the reference).  Every element (|x| < 2^14: an r^2 or
+ * S_AB mean) is rounded once to a multiple of 2^-40 and the integers are summed, so the total does not depend on how
+ * the columns are split over blocks, launches or GPUs.  out4: dev [rows][4] doubles = {sum l2, sum l1, sum l0, count
+ * of elements that were not finite or >= 2^14}, the integer as three 20-bit limbs (exact as doubles for up to 2^32
+ * columns in the whole job, so they survive a FP64 SUM all-reduce).  mcmc_fixed_sum_value (host) turns a limb triple,
+ * possibly summed over launches / GPUs, into the sum with ONE rounding.                                        */
+size_t mcmc_row_sum_fixed_workspace_bytes(uint32_t rows);
+int mcmc_launch_row_sum_fixed_f32(const float *x, uint32_t rows, uint64_t cols, double *out4, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+double mcmc_fixed_sum_value(const double *limbs3);
+
 /* ------------------------------------------------------------------ */
 /* Host statistics with the reference's exact arithmetic.               */
 /* Statistics.cuh:7-42,63-87 (FP32 Kahan) */
@@ -388,6 +400,55 @@ int mcmc_stepsize_run(const mcmc_target *target, int precision, int accept_rule,
 int mcmc_tune_stepsize(const mcmc_target *target, double lo, double hi, int n_widths, uint64_t n_chains,
                        uint64_t n_warmup, uint64_t n_steps, uint64_t seed, double x0, double *widths,
                        double *acceptance, double *tau_int, double *best_width);
+
+/* ------------------------------------------------------------------ */
+/* Layer C -- the two drivers on several GPUs of ONE node (north_star: "chains are partitioned across the 8 GPUs ...
+ * only sufficient statistics are combined with one RCCL all-reduce per batch").  The reference is single-GPU; its
+ * analogue of the exchange is the host Average over threads and runs (main.cu:221-223,253-258,359,384-389).
+ * A "shard" is a contiguous, balanced range of GLOBAL event / chain ids on one device (shard r of W owns
+ * [r*base + min(r, extra), ...) with base = n / W, extra = n % W: the first `extra` shards hold one id more); every
+ * shard queues all its launches on its own stream from its own host thread and leaves its sufficient statistics in
+ * one device vector; ONE all-reduce (SUM, FP64) of that vector ends the batch.
+ *   MCMC_REDUCE_RCCL  librccl, loaded at run time: ncclCommInitAll over the shards' devices + one grouped
+ *                     ncclAllReduce(double, sum) on the shards' streams (needs one device per shard);
+ *   MCMC_REDUCE_HOST  every shard copies its vector back and the host adds them in shard order;
+ *   MCMC_REDUCE_AUTO  RCCL when librccl loads, there are >= 2 shards and no two share a device; else the host.
+ * Several shards may name the same device (a one-GPU box rehearsing the partition; host reduction only).
+ * xsection payloads are integers held as doubles (hit counts; S_AB / r^2 sums as fixed-point limbs,
+ * mcmc_launch_row_sum_fixed_f32): every result of mcmc_multi_* is bit-identical for any number of shards.      */
+#define MCMC_REDUCE_AUTO (-1)
+#define MCMC_REDUCE_HOST 0
+#define MCMC_REDUCE_RCCL 1
+
+typedef struct mcmc_multi_s *mcmc_multi;
+
+/* cfg as for mcmc_create: cfg->totalBlocks * cfg->threadsPerBlock is the WHOLE job's event count (main.cu:89),
+ * partitioned over devices[0 .. n_shards); cfg->device is ignored, cfg->event_offset is the job's first id.    */
+int mcmc_multi_create(const mcmc_config *cfg, const int *devices, int n_shards, int reduce, mcmc_multi *out);
+int mcmc_multi_destroy(mcmc_multi m);
+/* n_shards, the reduction in use (MCMC_REDUCE_HOST / _RCCL) and each shard's first id / id count (any may be NULL) */
+int mcmc_multi_info(mcmc_multi m, int *n_shards, int *reduce_used, uint64_t *offsets, uint64_t *counts);
+/* the Layer B handle of one shard (owned by `m`; e.g. for mcmc_get_state), or NULL */
+mcmc_handle mcmc_multi_shard(mcmc_multi m, int shard);
+int mcmc_multi_warmup(mcmc_multi m, float stepsize, int iterations);   /* main.cu:149-152 on every shard */
+int mcmc_multi_init_from_pdf(mcmc_multi m);                            /* mcmc_init_from_pdf on every shard */
+/* mcmc_run_rms / mcmc_run_sab_scan / mcmc_run_inel_scan over all shards: the same outputs, evaluated on the
+ * all-reduced sums (the run mean of main.cu:221-223,359 is total / totalThreads of the whole job).            */
+int mcmc_multi_run_rms(mcmc_multi m, float *rms, float *rms_stderr);
+int mcmc_multi_run_sab_scan(mcmc_multi m, float *b, float *S_AB, float *S_AB_stderr, double *p_inel, float dmax2);
+int mcmc_multi_run_inel_scan(mcmc_multi m, float *b, double *p_inel, double *p_inel_stderr, float dmax2);
+
+/* mcmc_stepsize_run with the chains partitioned over devices[0 .. n_shards): one all-reduce of the
+ * [launches][n_coords][MCMC_STATS_LEN(n_lags)] statistics (FP64 sums over chains: equal across partitions to
+ * FP64 rounding).  samples_host needs n_shards == 1.  mcmc_stepsize_run is this call on the current device.
+ * FP32 windows longer than 65536 steps run as ring-carried launches of at most that length (the FP32 kernels
+ * keep their lag products in FP32 per launch, see mcmc_chain_run) whose statistics are added in FP64; the
+ * accumulators are centred on the target's mean (quadrature), not on x0.                                      */
+int mcmc_stepsize_run_multi(const mcmc_target *target, int precision, int accept_rule, int math_mode, double step,
+                            uint64_t n_chains, uint32_t n_coords, uint64_t n_warmup, uint64_t n_steps, uint32_t n_lags,
+                            uint64_t seed, double x0, const int *devices, int n_shards, int reduce,
+                            mcmc_chain_summary *summary /* [n_coords] */, double *rho /* [n_coords][n_lags] or NULL */,
+                            void *samples_host /* or NULL */);
 
 /* Isotope name ("PB-208", "208-pb") -> Z and A: NuclearZAndA, xsection/tools/MCMCMacro.py:63-83
  * (used by IntegrationSettings.SetIsotopeA/B, :145-157: protons = Z, neutrons = A - Z). */

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../host/output.hpp"
+#include "handle.hpp"
 #include "host_common.hpp"
 
 #pragma clang fp contract(off)
@@ -188,26 +189,7 @@ extern "C" int mcmc_isotope(const char *name, int *Z, int *A)
 }
 
 // ---------------------------------------------------------------------
-// Handle.
-struct mcmc_handle_s {
-    mcmc_config cfg;
-    int nA, nB, nN;
-    uint64_t T;
-    hipStream_t stream;
-    float *d_prev;
-    mcmc_target *d_targets;
-    float *d_result;   // [nN][T]
-    double *d_means;   // [nN] + [4] hits
-    void *d_ws;
-    size_t ws_bytes;
-    double *d_scan;    // per-launch results of mcmc_run_rms / mcmc_run_sab_scan
-    size_t scan_len;
-    uint64_t sweeps_done;
-    int uniform_kind;
-    char outDir[512];  // copies of cfg.outDir / cfg.outFile (the caller's strings need not outlive mcmc_create)
-    char outFile[256];
-};
-
+// Handle (struct mcmc_handle_s: handle.hpp).
 extern "C" void mcmc_config_default(mcmc_config *c)
 {
     if (!c) return;
@@ -240,28 +222,6 @@ extern "C" void mcmc_config_default(mcmc_config *c)
 
 namespace {
 
-mcmc_xs_args xs_args(mcmc_handle h, float stepsize)
-{
-    mcmc_xs_args a{};
-    a.nNucleonsA = h->nA;
-    a.nNucleonsB = h->nB;
-    a.totalThreads = h->T;
-    a.targets = h->d_targets;
-    a.prevSample = h->d_prev;
-    a.stepsize = stepsize;
-    a.accept_rule = h->cfg.accept_rule;
-    a.math_mode = h->cfg.math_mode;
-    a.uniform_kind = h->uniform_kind;
-    a.seed = h->cfg.seed;
-    a.step_offset = h->sweeps_done;
-    a.event_offset = h->cfg.event_offset;
-    a.sigmaNN = h->cfg.sigmaNN;
-    a.beta = h->cfg.beta;
-    a.workspace = h->d_ws;
-    a.workspace_bytes = h->ws_bytes;
-    return a;
-}
-
 void free_handle(mcmc_handle h)
 {
     if (!h) return;
@@ -292,9 +252,17 @@ int ensure_scan_buffer(mcmc_handle h, size_t len)
 extern "C" int mcmc_create(const mcmc_config *cfg, mcmc_handle *out)
 {
     if (!cfg || !out) return set_error(MCMC_EINVAL, "null pointer");
+    if (cfg->totalBlocks <= 0 || cfg->threadsPerBlock <= 0) return set_error(MCMC_EINVAL, "totalBlocks and threadsPerBlock must be > 0");
+    return create_handle(cfg, (uint64_t)cfg->totalBlocks * (uint64_t)cfg->threadsPerBlock, out); // main.cu:89
+}
+
+// `events` = the handle's share of totalThreads (all of them for mcmc_create; a partition of them per GPU for mcmc_multi_create)
+int mcmc::create_handle(const mcmc_config *cfg, uint64_t events, mcmc_handle *out)
+{
+    if (!cfg || !out) return set_error(MCMC_EINVAL, "null pointer");
+    if (events == 0) return set_error(MCMC_EINVAL, "a handle needs at least one event");
     if (cfg->nNeutronA < 0 || cfg->nProtonA < 0 || cfg->nNeutronB < 0 || cfg->nProtonB < 0)
         return set_error(MCMC_EINVAL, "negative nucleon count");
-    if (cfg->totalBlocks <= 0 || cfg->threadsPerBlock <= 0) return set_error(MCMC_EINVAL, "totalBlocks and threadsPerBlock must be > 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(MCMC_ENODEV, "no HIP device");
     MCMC_HIP_CHECK(hipSetDevice(cfg->device));
@@ -304,7 +272,7 @@ extern "C" int mcmc_create(const mcmc_config *cfg, mcmc_handle *out)
     h->nA = cfg->nNeutronA + cfg->nProtonA;
     h->nB = cfg->nNeutronB + cfg->nProtonB;
     h->nN = h->nA + h->nB;
-    h->T = (uint64_t)cfg->totalBlocks * (uint64_t)cfg->threadsPerBlock; // main.cu:89
+    h->T = events;
     if (h->nN == 0) { delete h; return set_error(MCMC_EINVAL, "no nucleons"); }
     std::snprintf(h->outDir, sizeof h->outDir, "%s", cfg->outDir ? cfg->outDir : "./");
     std::snprintf(h->outFile, sizeof h->outFile, "%s", cfg->outFile ? cfg->outFile : "out");
@@ -573,151 +541,5 @@ extern "C" int mcmc_get_state(mcmc_handle h, float *host_out)
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
     MCMC_HIP_CHECK(hipMemcpy(host_out, h->d_prev, sizeof(float) * h->nN * h->T, hipMemcpyDeviceToHost));
-    return MCMC_OK;
-}
-
-// ---------------------------------------------------------------------
-// stepsize driver in one call (stepsize/src/main.cpp:17-30 for many chains).  The device buffers live in a small
-// holder so that the step-size study (mcmc_tune_stepsize) allocates once for all its widths.
-namespace {
-struct StepsizeBuffers {
-    void *d_state = nullptr, *d_ws = nullptr, *d_samples = nullptr;
-    double *d_stats = nullptr;
-    size_t state_bytes = 0, ws_bytes = 0, samples_bytes = 0, stats_bytes = 0;
-    std::vector<char> init;
-    ~StepsizeBuffers()
-    {
-        if (d_state) (void)hipFree(d_state);
-        if (d_ws) (void)hipFree(d_ws);
-        if (d_stats) (void)hipFree(d_stats);
-        if (d_samples) (void)hipFree(d_samples);
-    }
-    static hipError_t grow(void **p, size_t *have, size_t need)
-    {
-        if (*have >= need) return hipSuccess;
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-        *have = 0;
-        const hipError_t e = hipMalloc(p, need);
-        if (e == hipSuccess) *have = need;
-        return e;
-    }
-};
-
-int stepsize_run(StepsizeBuffers &B, const mcmc_target *target, int precision, int accept_rule, int math_mode, double step,
-                 uint64_t n_chains, uint32_t n_coords, uint64_t n_warmup, uint64_t n_steps, uint32_t n_lags, uint64_t seed,
-                 double x0, mcmc_chain_summary *summary, double *rho, void *samples_host)
-{
-    if (!target || !summary) return set_error(MCMC_EINVAL, "null pointer");
-    if (n_chains == 0 || n_coords == 0 || n_steps == 0) return set_error(MCMC_EINVAL, "n_chains, n_coords and n_steps must be > 0");
-    if (precision != 32 && precision != 64) return set_error(MCMC_EINVAL, "precision must be 32 or 64");
-    const size_t esz = precision == 64 ? 8 : 4;
-    const size_t nstate = (size_t)n_chains * n_coords;
-    const int len = MCMC_STATS_LEN(n_lags);
-
-    mcmc_chain_args a{};
-    a.n_chains = n_chains;
-    a.n_coords = n_coords;
-    a.n_lags = n_lags;
-    a.step_size = step;
-    a.center = 0.0;
-    a.target = *target;
-    a.precision = precision;
-    a.accept_rule = accept_rule;
-    a.math_mode = math_mode;
-    a.seed = seed;
-
-    std::vector<double> hstats((size_t)n_coords * len);
-    const size_t ws_bytes = mcmc_chain_workspace_bytes(&a);
-    MCMC_HIP_CHECK(StepsizeBuffers::grow(&B.d_state, &B.state_bytes, nstate * esz));
-    MCMC_HIP_CHECK(StepsizeBuffers::grow(&B.d_ws, &B.ws_bytes, ws_bytes));
-    MCMC_HIP_CHECK(StepsizeBuffers::grow((void **)&B.d_stats, &B.stats_bytes, sizeof(double) * hstats.size()));
-    if (samples_host) MCMC_HIP_CHECK(StepsizeBuffers::grow(&B.d_samples, &B.samples_bytes, (size_t)n_steps * nstate * esz));
-    a.workspace = B.d_ws;
-    a.workspace_bytes = ws_bytes;
-    // x0 (metropolis.hpp:29 `double r = 1`)
-    B.init.resize(nstate * esz);
-    for (size_t i = 0; i < nstate; i++) {
-        if (precision == 64) ((double *)B.init.data())[i] = x0;
-        else ((float *)B.init.data())[i] = (float)x0;
-    }
-    MCMC_HIP_CHECK(hipMemcpyAsync(B.d_state, B.init.data(), B.init.size(), hipMemcpyHostToDevice, nullptr));
-    a.state = B.d_state;
-    a.stats = B.d_stats;
-    int rc;
-    if (n_warmup > 0) {
-        a.n_lags = 0;
-        a.n_steps = n_warmup;
-        a.step_offset = 0;
-        a.window_start = 1;
-        if ((rc = mcmc_chain_run(&a, nullptr)) != MCMC_OK) return rc;
-    }
-    a.n_lags = n_lags;
-    a.n_steps = n_steps;
-    a.step_offset = n_warmup;
-    a.window_start = 1;
-    a.samples = samples_host ? B.d_samples : nullptr;
-    // centre the accumulators on the target's bulk to limit cancellation (statistics are shift-invariant)
-    a.center = x0;
-    if ((rc = mcmc_chain_run(&a, nullptr)) != MCMC_OK) return rc;
-    MCMC_HIP_CHECK(hipMemcpyAsync(hstats.data(), B.d_stats, sizeof(double) * hstats.size(), hipMemcpyDeviceToHost, nullptr));
-    if (samples_host)
-        MCMC_HIP_CHECK(hipMemcpyAsync(samples_host, B.d_samples, (size_t)n_steps * nstate * esz, hipMemcpyDeviceToHost, nullptr));
-    MCMC_HIP_CHECK(hipStreamSynchronize(nullptr));
-    for (uint32_t c = 0; c < n_coords; c++) {
-        rc = mcmc_stats_finalize(&hstats[(size_t)c * len], n_lags, n_chains, n_steps, a.center, &summary[c],
-                                 rho ? rho + (size_t)c * n_lags : nullptr);
-        if (rc) return rc;
-    }
-    return MCMC_OK;
-}
-} // namespace
-
-extern "C" int mcmc_stepsize_run(const mcmc_target *target, int precision, int accept_rule, int math_mode, double step,
-                                 uint64_t n_chains, uint32_t n_coords, uint64_t n_warmup, uint64_t n_steps, uint32_t n_lags,
-                                 uint64_t seed, double x0, mcmc_chain_summary *summary, double *rho, void *samples_host)
-{
-    StepsizeBuffers B;
-    return stepsize_run(B, target, precision, accept_rule, math_mode, step, n_chains, n_coords, n_warmup, n_steps, n_lags, seed,
-                        x0, summary, rho, samples_host);
-}
-
-// The step-size study of the stepsize executable (stepsize/src/main.cpp:14-36: acceptance and lag-k
-// autocorrelation per proposal width) run on the device for a grid of widths, and the width of least
-// integrated autocorrelation time 1 + 2 sum_k rho_k (the notebook's efficiency, StepSizeAnalysis.ipynb
-// cell 1), refined by a parabola through the grid minimum and its neighbours.  Closes the loop to
-// xsection, whose width is the constant 2.2f of main.cu:149,197,335.
-extern "C" int mcmc_tune_stepsize(const mcmc_target *target, double lo, double hi, int n_widths, uint64_t n_chains,
-                                  uint64_t n_warmup, uint64_t n_steps, uint64_t seed, double x0, double *widths,
-                                  double *acceptance, double *tau_int, double *best_width)
-{
-    if (!target || !best_width) return set_error(MCMC_EINVAL, "null pointer");
-    if (!(lo > 0.0) || !(hi > lo) || n_widths < 3) return set_error(MCMC_EINVAL, "need 0 < lo < hi and n_widths >= 3");
-    if (n_steps <= (uint64_t)MCMC_MAX_LAGS + 1) return set_error(MCMC_EINVAL, "n_steps must exceed MCMC_MAX_LAGS + 1");
-    std::vector<double> w(n_widths), acc(n_widths), tau(n_widths);
-    StepsizeBuffers B; // one allocation for all widths
-    for (int i = 0; i < n_widths; ++i) {
-        w[i] = lo + (hi - lo) * i / (n_widths - 1);
-        mcmc_chain_summary s;
-        const int rc = stepsize_run(B, target, 32, MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, w[i], n_chains, 1, n_warmup, n_steps,
-                                    MCMC_MAX_LAGS, seed, x0, &s, nullptr, nullptr);
-        if (rc) return rc;
-        acc[i] = s.acceptance;
-        tau[i] = s.tau_int;
-    }
-    int k = 0;
-    for (int i = 1; i < n_widths; ++i)
-        if (tau[i] < tau[k]) k = i;
-    double best = w[k];
-    if (k > 0 && k + 1 < n_widths) { // vertex of the parabola through (w[k-1..k+1], tau[k-1..k+1]); equal spacing
-        const double d = tau[k - 1] - 2.0 * tau[k] + tau[k + 1];
-        if (d > 0.0) best = w[k] + 0.5 * (w[k] - w[k - 1]) * (tau[k - 1] - tau[k + 1]) / d;
-    }
-    for (int i = 0; i < n_widths; ++i) {
-        if (widths) widths[i] = w[i];
-        if (acceptance) acceptance[i] = acc[i];
-        if (tau_int) tau_int[i] = tau[i];
-    }
-    *best_width = best;
     return MCMC_OK;
 }

@@ -1059,4 +1059,57 @@ static __global__ void row_final_kernel(const double *partials, double *out, uin
 
 static __global__ void set_double_kernel(double *dst, double v) { *dst = v; }
 
+// Sharding-invariant row sums (the multi-GPU reduction of main.cu:221-223,359): every element is rounded ONCE to a
+// multiple of 2^-FIXED_FRAC (|x| < 2^14: an r^2 mean or an S_AB mean) and the integers are summed -- integer addition
+// is associative, so the total does not depend on how the columns are split over blocks, launches or GPUs.  The
+// 54-bit integer q = l2 2^40 + l1 2^20 + l0 (l0, l1 in [0, 2^20), l2 signed) travels as three limb sums; each stays
+// below 2^52 for up to 2^32 columns in the whole job, so the limbs are exact as doubles and survive a FP64 SUM
+// all-reduce.  out[row] = {sum l2, sum l1, sum l0, count of elements that were not finite or >= 2^14}.
+constexpr int FIXED_FRAC = 40;
+constexpr int FIXED_LIMB = 20;
+
+static __global__ __launch_bounds__(256) void row_fixed_partial_kernel(const float *x, uint64_t cols, int64_t *partials)
+{
+    __shared__ int64_t sw[4][4];
+    const uint32_t row = blockIdx.y;
+    const uint32_t chunk = blockIdx.x;
+    const uint64_t per = (cols + RR_CHUNKS - 1) / RR_CHUNKS;
+    const uint64_t c0 = (uint64_t)chunk * per;
+    const uint64_t c1 = c0 + per < cols ? c0 + per : cols;
+    int64_t a2 = 0, a1 = 0, a0 = 0, bad = 0;
+    for (uint64_t c = c0 + threadIdx.x; c < c1; c += 256) {
+        const float v = x[(uint64_t)row * cols + c];
+        if (!(__builtin_fabsf(v) < 16384.0f)) {
+            ++bad;
+            continue;
+        }
+        const int64_t q = __float2ll_rn(v * 0x1p40f); // the scaling is exact; one rounding, to 2^-40
+        a0 += q & ((1ll << FIXED_LIMB) - 1);
+        a1 += (q >> FIXED_LIMB) & ((1ll << FIXED_LIMB) - 1);
+        a2 += q >> (2 * FIXED_LIMB);
+    }
+    int64_t v[4] = {a2, a1, a0, bad};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+        if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        partials[((uint64_t)row * RR_CHUNKS + chunk) * 4 + k] = sw[0][k] + sw[1][k] + sw[2][k] + sw[3][k];
+    }
+}
+
+static __global__ void row_fixed_final_kernel(const int64_t *partials, double *out, uint32_t rows)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 4) return;
+    const uint32_t row = i >> 2, k = i & 3;
+    int64_t tot = 0;
+    for (int c = 0; c < RR_CHUNKS; ++c) tot += partials[((uint64_t)row * RR_CHUNKS + c) * 4 + k];
+    out[(uint64_t)row * 4 + k] = (double)tot; // |tot| < 2^52: exact
+}
+
 } // namespace mcmc

@@ -461,3 +461,31 @@ extern "C" int mcmc_launch_row_mean_f32(const float *x, uint32_t rows, uint64_t 
     if (!x || !out || rows == 0 || cols == 0) return set_error(MCMC_EINVAL, "bad row_mean arguments");
     return row_reduce<float>(x, rows, cols, 1.0 / (double)cols, out, 0, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+// Sharding-invariant row sums for the multi-GPU reduction (row_fixed_partial_kernel, xs_kernel.hpp): no reference
+// counterpart beyond the host Average it feeds (main.cu:221-223,359).
+extern "C" size_t mcmc_row_sum_fixed_workspace_bytes(uint32_t rows) { return align_up((size_t)rows * RR_CHUNKS * 4 * sizeof(int64_t), 256); }
+
+extern "C" int mcmc_launch_row_sum_fixed_f32(const float *x, uint32_t rows, uint64_t cols, double *out4, void *workspace,
+                                             size_t workspace_bytes, void *stream)
+{
+    if (!x || !out4 || rows == 0 || cols == 0) return set_error(MCMC_EINVAL, "bad row_sum_fixed arguments");
+    if (cols > (1ull << 32)) return set_error(MCMC_EINVAL, "row_sum_fixed: at most 2^32 columns (the limb sums stay exact doubles)");
+    if (!workspace || workspace_bytes < mcmc_row_sum_fixed_workspace_bytes(rows))
+        return set_error(MCMC_ENOMEM, "workspace smaller than mcmc_row_sum_fixed_workspace_bytes()");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(row_fixed_partial_kernel, dim3(RR_CHUNKS, rows), dim3(256), 0, s, x, cols, (int64_t *)workspace);
+    MCMC_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(row_fixed_final_kernel, dim3((rows * 4 + 63) / 64), dim3(64), 0, s, (const int64_t *)workspace, out4, rows);
+    MCMC_HIP_CHECK(hipGetLastError());
+    return MCMC_OK;
+}
+
+// value of a limb triple {sum l2, sum l1, sum l0} (possibly summed over launches / GPUs): one rounding, from the exact integer
+extern "C" double mcmc_fixed_sum_value(const double *limbs3)
+{
+    if (!limbs3) return 0.0;
+    const __int128 q = ((__int128)(long long)limbs3[0] << (2 * FIXED_LIMB)) + ((__int128)(long long)limbs3[1] << FIXED_LIMB) +
+                       (__int128)(long long)limbs3[2];
+    return (double)q * 0x1p-40; // __int128 -> double rounds once; the scaling is exact
+}

@@ -33,6 +33,8 @@ struct Options {
     double x0 = 1.0; // metropolis.hpp:29
     std::string outdir = "./";
     bool samples = false;
+    std::vector<int> devices; // --devices 0,1,...: the chains partitioned over these GPUs (mcmc_stepsize_run_multi)
+    int reduce = MCMC_REDUCE_AUTO;
 };
 
 void usage()
@@ -41,7 +43,8 @@ void usage()
               "                [--first K] [--last K] [--stride K]   widths K/100 (default 1..500)\n"
               "                [--precision 32|64] [--rule recip|shortcircuit|nodiv|log|cross] [--math precise|fast]\n"
               "                [--target ws|r2ws|gauss|r2gauss] [--p0 X] [--p1 X] [--x0 X] [--seed S]\n"
-              "                [--outdir DIR] [--samples]   (samples_<k>.txt of chain 0, needs --chains 1)");
+              "                [--outdir DIR] [--samples]   (samples_<k>.txt of chain 0, needs --chains 1)\n"
+              "                [--devices 0,1,...] [--reduce auto|host|rccl]   chains partitioned over GPUs, one all-reduce per width");
 }
 
 bool parse(int argc, char **argv, Options &o)
@@ -71,6 +74,20 @@ bool parse(int argc, char **argv, Options &o)
         else if (a == "--p1") o.target.p1 = (float)std::atof(val("--p1"));
         else if (a == "--outdir") o.outdir = val("--outdir");
         else if (a == "--samples") o.samples = true;
+        else if (a == "--devices") {
+            const std::string v = val("--devices");
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                const size_t c = v.find(',', pos);
+                const std::string tok = v.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+                if (!tok.empty()) o.devices.push_back(std::atoi(tok.c_str()));
+                if (c == std::string::npos) break;
+                pos = c + 1;
+            }
+        } else if (a == "--reduce") {
+            const std::string r = val("--reduce");
+            o.reduce = r == "host" ? MCMC_REDUCE_HOST : r == "rccl" ? MCMC_REDUCE_RCCL : MCMC_REDUCE_AUTO;
+        }
         else if (a == "--math") o.math = std::strcmp(val("--math"), "fast") == 0 ? MCMC_MATH_FAST : MCMC_MATH_PRECISE;
         else if (a == "--rule") {
             const std::string r = val("--rule");
@@ -130,8 +147,12 @@ int main(int argc, char **argv)
                 sp = samples32.data();
             }
         }
-        const int rc = mcmc_stepsize_run(&o.target, o.precision, o.rule, o.math, width, o.chains, o.coords, o.warmup,
-                                         o.iterations, o.lags, o.seed, o.x0, summary.data(), rho.data(), sp);
+        const int rc = o.devices.empty()
+                           ? mcmc_stepsize_run(&o.target, o.precision, o.rule, o.math, width, o.chains, o.coords, o.warmup, o.iterations,
+                                               o.lags, o.seed, o.x0, summary.data(), rho.data(), sp)
+                           : mcmc_stepsize_run_multi(&o.target, o.precision, o.rule, o.math, width, o.chains, o.coords, o.warmup,
+                                                     o.iterations, o.lags, o.seed, o.x0, o.devices.data(), (int)o.devices.size(),
+                                                     o.reduce, summary.data(), rho.data(), sp);
         if (rc != MCMC_OK) {
             std::fprintf(stderr, "stepsize: mcmc_stepsize_run failed (%d): %s\n", rc, mcmc_last_error());
             return 1;

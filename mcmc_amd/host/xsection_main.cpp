@@ -12,6 +12,9 @@
 //   totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix
 //   b0 db ndbs seed stepsize sigmaNN beta outDir outFile integrateRMS integrateSAB
 //   blackDisk=1 (adds the hit-test inelastic probability, d < sqrt(sigmaNN/pi))  math=fast|precise
+//   devices=0,1,...  reduce=auto|host|rccl : the events (totalBlocks x threadsPerBlock) partitioned over these GPUs, one
+//   host thread and stream per GPU, ONE all-reduce of the scan's sufficient statistics (mcmc_multi_*, include/mcmc_hip.h
+//   Layer C); results are bit-identical for any device list.  Without devices=: the one-GPU handle on `device`.
 //
 // Results: <outDir><outFile>.RMS.csv and .S_AB.csv with the reference's TTree columns
 // (IntegrationOutputHandler.cuh:83-87,109-112), and sigma_tot / sigma_el / sigma_rxn from the
@@ -43,6 +46,20 @@ bool parse_pdf(const std::string &v, mcmc_target &t)
     return true;
 }
 
+std::vector<int> parse_devices(const std::string &v)
+{
+    std::vector<int> d;
+    size_t pos = 0;
+    while (pos <= v.size()) {
+        const size_t c = v.find(',', pos);
+        const std::string tok = v.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+        if (!tok.empty()) d.push_back(std::atoi(tok.c_str()));
+        if (c == std::string::npos) break;
+        pos = c + 1;
+    }
+    return d;
+}
+
 void die(const char *what)
 {
     std::fprintf(stderr, "xsection: %s: %s\n", what, mcmc_last_error());
@@ -58,6 +75,8 @@ int main(int argc, char **argv)
     std::string outDir = "./", outFile = "out"; // main.cu:73-74 ("../data/", "out.root")
     bool integrateRMS = true, integrateSAB = true, blackDisk = false, inelOnly = false; // main.cu:81-82
     bool autoStep = false, randomStart = false;
+    std::vector<int> devices; // devices=...: the multi-GPU path
+    int reduce = MCMC_REDUCE_AUTO;
 
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -69,7 +88,8 @@ int main(int argc, char **argv)
             }
             std::puts("usage: xsection [name=value ...]   names: nNeutronA nProtonA nNeutronB nProtonB isotopeA isotopeB pdf pdfA\n"
                       "       pdfB totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix b0 db ndbs seed stepsize\n"
-                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk inelOnly randomStart rule math device");
+                      "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk inelOnly randomStart rule math device\n"
+                      "       devices=0,1,... reduce=auto|host|rccl");
             return a == "--help" || a == "-h" ? 0 : 2;
         }
         const std::string k = a.substr(0, eq), v = a.substr(eq + 1);
@@ -108,6 +128,8 @@ int main(int argc, char **argv)
         else if (k == "sigmaNN") cfg.sigmaNN = fv;
         else if (k == "beta") cfg.beta = fv;
         else if (k == "device") cfg.device = iv;
+        else if (k == "devices") devices = parse_devices(v);
+        else if (k == "reduce") reduce = v == "host" ? MCMC_REDUCE_HOST : v == "rccl" ? MCMC_REDUCE_RCCL : MCMC_REDUCE_AUTO;
         else if (k == "rule") // acceptance test: the reference's p'(1/p) >= U, the reciprocal-free forms of p' >= U p, or log space
             cfg.accept_rule = v == "cross" ? MCMC_ACCEPT_CROSS : v == "nodiv" ? MCMC_ACCEPT_NODIV
                               : v == "log" ? MCMC_ACCEPT_LOG : MCMC_ACCEPT_RECIP;
@@ -156,20 +178,31 @@ int main(int argc, char **argv)
         std::printf("proposal width tuned on the device: %.3f (reference constant: 2.2)\n", best);
     }
 
+    // one GPU: the Layer B handle; devices=...: the same calls on the sharded job (Layer C)
     mcmc_handle h = nullptr;
-    if (mcmc_create(&cfg, &h)) die("mcmc_create");
+    mcmc_multi m = nullptr;
+    if (devices.empty()) {
+        if (mcmc_create(&cfg, &h)) die("mcmc_create");
+    } else {
+        if (mcmc_multi_create(&cfg, devices.data(), (int)devices.size(), reduce, &m)) die("mcmc_multi_create");
+        int used = 0;
+        std::vector<uint64_t> cnt(devices.size());
+        mcmc_multi_info(m, nullptr, &used, nullptr, cnt.data());
+        std::printf("%zu shards (events per shard: %llu ... %llu), statistics reduced by %s\n", devices.size(),
+                    (unsigned long long)cnt.front(), (unsigned long long)cnt.back(), used == MCMC_REDUCE_RCCL ? "RCCL all-reduce" : "host sum");
+    }
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 
-    if (randomStart && mcmc_init_from_pdf(h)) die("mcmc_init_from_pdf"); // main.cu:144-148
+    if (randomStart && (m ? mcmc_multi_init_from_pdf(m) : mcmc_init_from_pdf(h))) die("mcmc_init_from_pdf"); // main.cu:144-148
     auto t0 = now();
-    if (mcmc_warmup(h, cfg.stepsize, cfg.samplesForMix)) die("mcmc_warmup"); // main.cu:149
+    if (m ? mcmc_multi_warmup(m, cfg.stepsize, cfg.samplesForMix) : mcmc_warmup(h, cfg.stepsize, cfg.samplesForMix)) die("mcmc_warmup"); // main.cu:149
     std::printf("Metropolis chain warm-up (%d sweeps): %.1f ms\n", cfg.samplesForMix, ms(t0, now()));
 
     if (integrateRMS) { // main.cu:157-286
         std::vector<float> rms(nNucleons), err(nNucleons);
         t0 = now();
-        if (mcmc_run_rms(h, rms.data(), err.data())) die("mcmc_run_rms");
+        if (m ? mcmc_multi_run_rms(m, rms.data(), err.data()) : mcmc_run_rms(h, rms.data(), err.data())) die("mcmc_run_rms");
         const double t = ms(t0, now());
         std::printf("RMS results (%.1f ms, %.3g proposals/s)\n", t, totalSamples * nNucleons / (t * 1e-3));
         for (int n = 0; n < nNucleons; ++n) std::printf("Nucleon %d has RMS = %g +/- %g\n", n, rms[n], err[n]); // main.cu:264
@@ -185,7 +218,9 @@ int main(int argc, char **argv)
         std::vector<double> pin(n), perr(n);
         const float dmax2 = cfg.sigmaNN / 3.14159265358979f;
         t0 = now();
-        if (mcmc_run_inel_scan(h, b.data(), pin.data(), perr.data(), dmax2)) die("mcmc_run_inel_scan");
+        if (m ? mcmc_multi_run_inel_scan(m, b.data(), pin.data(), perr.data(), dmax2)
+              : mcmc_run_inel_scan(h, b.data(), pin.data(), perr.data(), dmax2))
+            die("mcmc_run_inel_scan");
         const double t = ms(t0, now());
         std::printf("inelastic scan: %d impact parameters in %.1f ms (%.3g event samples/s)\n", n, t, totalSamples * n / (t * 1e-3));
         if (!mcmc_host::write_inel_csv(b, pin, perr, outDir + outFile + ".inel.csv")) {
@@ -208,7 +243,9 @@ int main(int argc, char **argv)
         std::vector<double> pin(n);
         const float dmax2 = cfg.sigmaNN / 3.14159265358979f; // black disk: sigma_NN = pi d_max^2
         t0 = now();
-        if (mcmc_run_sab_scan(h, b.data(), S.data(), E.data(), blackDisk ? pin.data() : nullptr, dmax2)) die("mcmc_run_sab_scan");
+        if (m ? mcmc_multi_run_sab_scan(m, b.data(), S.data(), E.data(), blackDisk ? pin.data() : nullptr, dmax2)
+              : mcmc_run_sab_scan(h, b.data(), S.data(), E.data(), blackDisk ? pin.data() : nullptr, dmax2))
+            die("mcmc_run_sab_scan");
         const double t = ms(t0, now());
         std::printf("S_AB scan: %d impact parameters in %.1f ms (%.3g event samples/s, %.3g nominal pair terms/s)\n", n, t,
                     totalSamples * n / (t * 1e-3), totalSamples * n * nNucleonsA * nNucleonsB / (t * 1e-3));
@@ -229,6 +266,6 @@ int main(int argc, char **argv)
             }
         }
     }
-    if (mcmc_destroy(h)) die("mcmc_destroy"); // main.cu:419-422
+    if (m ? mcmc_multi_destroy(m) : mcmc_destroy(h)) die("mcmc_destroy"); // main.cu:419-422
     return 0;
 }

@@ -16,6 +16,7 @@ ACCEPT_RECIP, ACCEPT_SHORTCIRCUIT, ACCEPT_NODIV, ACCEPT_LOG, ACCEPT_CROSS = 0, 1
 MATH_PRECISE, MATH_FAST = 0, 1
 MAX_LAGS = 49
 CHAIN_NOALLOC_MAX_BYTES = 8 << 20   # MCMC_CHAIN_NOALLOC_MAX_BYTES
+REDUCE_AUTO, REDUCE_HOST, REDUCE_RCCL = -1, 0, 1
 
 
 def stats_len(n_lags):
@@ -94,6 +95,10 @@ EXPORTS = [
     "mcmc_Average_f64", "mcmc_Variance_f64", "mcmc_AutoCorrelation_f64", "mcmc_cross_sections",
     "mcmc_config_default", "mcmc_create", "mcmc_destroy", "mcmc_warmup", "mcmc_integrate_r2",
     "mcmc_integrate_sab", "mcmc_run_rms", "mcmc_run_sab_scan", "mcmc_run_all", "mcmc_set_option", "mcmc_run_inel_scan", "mcmc_init_from_pdf", "mcmc_get_state", "mcmc_wait",
+    "mcmc_row_sum_fixed_workspace_bytes", "mcmc_launch_row_sum_fixed_f32", "mcmc_fixed_sum_value",
+    "mcmc_multi_create", "mcmc_multi_destroy", "mcmc_multi_info", "mcmc_multi_shard", "mcmc_multi_warmup",
+    "mcmc_multi_init_from_pdf", "mcmc_multi_run_rms", "mcmc_multi_run_sab_scan", "mcmc_multi_run_inel_scan",
+    "mcmc_stepsize_run_multi",
     "mcmc_stepsize_run", "mcmc_tune_stepsize", "mcmc_isotope", "mcmc_last_error", "mcmc_version", "mcmc_philox_rounds", "mcmc_device_count",
 ]
 
@@ -169,6 +174,25 @@ def _load():
     lib.mcmc_stepsize_run.argtypes = [P(Target), C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint32,
                                       C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, P(ChainSummary),
                                       P(C.c_double), C.c_void_p]
+    lib.mcmc_row_sum_fixed_workspace_bytes.restype = C.c_size_t
+    lib.mcmc_row_sum_fixed_workspace_bytes.argtypes = [C.c_uint32]
+    lib.mcmc_launch_row_sum_fixed_f32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p]
+    lib.mcmc_fixed_sum_value.restype = C.c_double
+    lib.mcmc_fixed_sum_value.argtypes = [P(C.c_double)]
+    lib.mcmc_multi_create.argtypes = [P(Config), P(C.c_int), C.c_int, C.c_int, P(C.c_void_p)]
+    lib.mcmc_multi_destroy.argtypes = [C.c_void_p]
+    lib.mcmc_multi_info.argtypes = [C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_uint64), P(C.c_uint64)]
+    lib.mcmc_multi_shard.restype = C.c_void_p
+    lib.mcmc_multi_shard.argtypes = [C.c_void_p, C.c_int]
+    lib.mcmc_multi_warmup.argtypes = [C.c_void_p, C.c_float, C.c_int]
+    lib.mcmc_multi_init_from_pdf.argtypes = [C.c_void_p]
+    lib.mcmc_multi_run_rms.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float)]
+    lib.mcmc_multi_run_sab_scan.argtypes = [C.c_void_p, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_double), C.c_float]
+    lib.mcmc_multi_run_inel_scan.argtypes = [C.c_void_p, P(C.c_float), P(C.c_double), P(C.c_double), C.c_float]
+    lib.mcmc_stepsize_run_multi.argtypes = [P(Target), C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint32,
+                                            C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_double, P(C.c_int), C.c_int,
+                                            C.c_int, P(ChainSummary), P(C.c_double), C.c_void_p]
     lib.mcmc_isotope.argtypes = [C.c_char_p, P(C.c_int), P(C.c_int)]
     lib.mcmc_tune_stepsize.argtypes = [P(Target), C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.c_uint64, C.c_double, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double)]
