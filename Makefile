@@ -98,3 +98,12 @@ ubench: tools/bin/ubench tools/bin/ubench2 tools/bin/ubench3 tools/bin/ubench_ca
 tools/bin/%: tools/%.hip
 	@mkdir -p tools/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
+
+# A/B builds of the lag kernel (tools/lag49_probe.py with MCMC_HIP_LIB=tools/bin/libmcmc_hip_lagab.so): only the r^2
+# Woods-Saxon chain kernels are rebuilt, with LAGAB_FLAGS (e.g. -DMCMC_LAGM_BLOCKS_PER_CU=4)
+LAGAB_FLAGS ?= -DMCMC_LAGM_BLOCKS_PER_CU=4
+lagab: $(LIB)
+	mkdir -p build/lagab tools/bin
+	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -DMCMC_KIND=1 $(LAGAB_FLAGS) -c $(CSRC)/chain_kind.hip -o build/lagab/chain_kind_1.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o tools/bin/libmcmc_hip_lagab.so $(filter-out $(OBJ)/chain_kind_1.o,$(OBJS)) build/lagab/chain_kind_1.o -ldl -lpthread
+.PHONY: lagab

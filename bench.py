@@ -61,6 +61,9 @@ def parse(argv=None):
     ap.add_argument("--math", default="fast", choices=["fast", "precise"])
     ap.add_argument("--lags", type=int, default=0, help="lag products inside the timed kernel (chain)")
     ap.add_argument("--nucleus", default="pb", choices=sorted(NUCLEI), help="nucleon workload: Pb-208 or Au-197")
+    ap.add_argument("--full", action="store_true",
+                    help="stress workload: write the whole 64-D state back every sweep (samples_full[sweep][coord][chain], the "
+                         "HBM-heavy form of configs[4]); the line's roofline is then the HBM one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-ess", action="store_true")
@@ -71,8 +74,10 @@ def parse(argv=None):
         ap.error("--gpus must be >= 1")
     if args.chains is None:
         args.chains = {"chain": 1 << 24, "nucleon": 1 << 22, "stress": 1 << 21}[args.workload]
+    if args.full and args.workload != "stress":
+        ap.error("--full belongs to --workload stress")
     if args.sweeps is None:
-        args.sweeps = 64 if args.workload == "stress" else 256
+        args.sweeps = (32 if args.full else 64) if args.workload == "stress" else 256
     if args.step_size is None:
         args.step_size = {"chain": 2.48, "nucleon": 2.2, "stress": 0.8}[args.workload]
     return args
@@ -166,6 +171,14 @@ def secondary(dev):
         t = timed(lambda: eng.run(S, samples=smp))
         out["chain_writeback_proposals_per_s"] = nc * C * S / t
         out["chain_writeback_algorithmic_GBps"] = (nc * C * S * 4 + 2 * 4 * nc * C) / t / 1e9
+        del eng, smp
+        # the headline workload under the log-space rule (north_star (1)) and under the reference's cached-reciprocal rule
+        for name, rule in (("log", L.ACCEPT_LOG), ("recip", L.ACCEPT_RECIP)):
+            eng = api.ChainEngine(nc, C, api.make_target(L.TARGET_R2WS, 2.0, 0.54), 2.48, precision=32, accept_rule=rule,
+                                  math_mode=L.MATH_FAST, center=2.3, device=dev)
+            t = timed(lambda: eng.run(256))
+            out[f"chain_{name}_rule_proposals_per_s"] = nc * C * 256 / t
+            del eng
     except Exception as e:  # the headline line must not depend on these
         out["error"] = f"{type(e).__name__}: {e}"
     return out
@@ -278,6 +291,12 @@ def cpu_reference_f64(step_size):
                       f"injected draws: RNG cost excluded), {dt:.2f} s"}
 
 
+def rng_name():
+    """The generator the loaded library was built with (MCMC_HIP_LIB may select the 7-round build)."""
+    from mcmc_amd import lib as L
+    return f"philox4x32-{L.lib.mcmc_philox_rounds()}"
+
+
 # ---------------------------------------------------------------------------------------------------
 # The three workloads: each returns an object with step() -> float64 statistics tensor (device),
 # launch() (the kernel launches alone, for the event bracket), and the constants of its bench line.
@@ -305,7 +324,7 @@ class ChainWorkload:
         return {"workload": f"mh_chain r2WoodsSaxon(2.0,0.54) x{a.coords} coords, {a.chains} chains/GPU, "
                             f"{a.sweeps} sweeps/launch, step {a.step_size}",
                 "chains_per_gpu": a.chains, "coords": a.coords, "sweeps_per_step": a.sweeps, "accept_rule": a.rule,
-                "math": a.math, "lags_in_kernel": a.lags, "rng": "philox4x32-10",
+                "math": a.math, "lags_in_kernel": a.lags, "rng": rng_name(),
                 "parallelism": f"chains sharded over {world} GPU(s)"}
 
     def estimates(self, st, world):
@@ -342,7 +361,7 @@ class NucleonWorkload:
         return {"workload": f"nucleon radial chains {a.nucleus.upper()}-{self.A} r2WoodsSaxon({self.c},{self.a}), "
                             f"{self.T} events x {self.A} nucleons/GPU, MCIntegrate_R2 {a.sweeps} samples/launch, step {a.step_size}",
                 "events_per_gpu": self.T, "nucleons": self.A, "chains_per_gpu": self.T * self.A, "coords": 1,
-                "sweeps_per_step": a.sweeps, "accept_rule": a.rule, "math": a.math, "rng": "philox4x32-10",
+                "sweeps_per_step": a.sweeps, "accept_rule": a.rule, "math": a.math, "rng": rng_name(),
                 "parallelism": f"events sharded over {world} GPU(s)"}
 
     def estimates(self, st, world):
@@ -362,6 +381,8 @@ class StressWorkload:
         self.eng = api.MvnEngine(args.chains, qd, qo, args.step_size, self.lag, math_mode=L.MATH_FAST, seed=314159265, x0=0.0,
                                  chain_offset=rank * args.chains, device=dev)
         self.obs = torch.empty((args.sweeps, args.chains), dtype=torch.float32, device=dev)
+        # --full: the whole state of every sweep, samples_full[sweep][coord][chain] (4 D bytes more per chain-sweep)
+        self.full = torch.empty((args.sweeps, self.D, args.chains), dtype=torch.float32, device=dev) if args.full else None
         # fill the lag ring first: a sweep reads its ring slot only from the window's sweep `lag` on, and the timed
         # launches are to carry all 12 B per chain-sweep (observable write, ring read, ring write)
         self.eng.run(self.lag + 24, window=(0, 1 << 40))
@@ -369,17 +390,20 @@ class StressWorkload:
         self.proposals_per_launch = args.chains * self.D * args.sweeps
         self.flop_per_proposal = FLOP_MVN_PROPOSAL
         # 12 B per chain-sweep (observable write, ring read, ring write) + state load/store per launch
-        self.algorithmic_bytes = args.chains * (args.sweeps * 12 + 2 * 4 * self.D)
+        self.algorithmic_bytes = args.chains * (args.sweeps * (12 + (4 * self.D if args.full else 0)) + 2 * 4 * self.D)
+        if args.full:
+            self.kernel = "mcmc::mvn_reg_kernel (full-state write-back)"
 
     def launch(self):
-        return self.eng.run(self.args.sweeps, window=(0, 1 << 40), samples_obs=self.obs)
+        return self.eng.run(self.args.sweeps, window=(0, 1 << 40), samples_obs=self.obs, samples_full=self.full)
 
     def config(self, world):
         a = self.args
+        wb = "full-state write-back" if a.full else "observable write-back"
         return {"workload": f"stress {self.D}-D Gaussian Sigma=0.9^|i-j|, {a.chains} chains/GPU, lag-{self.lag} ring in HBM, "
-                            f"observable write-back, {a.sweeps} sweeps/launch, step {a.step_size}",
+                            f"{wb}, {a.sweeps} sweeps/launch, step {a.step_size}",
                 "chains_per_gpu": a.chains, "coords": self.D, "sweeps_per_step": a.sweeps, "lag": self.lag,
-                "accept_rule": "log", "math": "fast", "rng": "philox4x32-10",
+                "accept_rule": "log", "math": "fast", "rng": rng_name(), "full_state_writeback": bool(a.full),
                 "parallelism": f"chains sharded over {world} GPU(s)"}
 
     def estimates(self, st, world):
@@ -486,8 +510,8 @@ def main(argv=None):
             roof["note"] = ("FP32 VALU-issue-bound (state in registers, no per-step HBM traffic). achieved = 24 algorithmic "
                             "FP32 flop per proposal (SURVEY 8d) / kernel time; Philox integer work and quarter-rate "
                             "transcendentals are not counted as flops, so frac understates VALU occupancy: valu_issue sets "
-                            "the issue cycles of the loop's instruction mix against the cycles measured with the shader clock "
-                            "of THIS run (DESIGN.md 4.1; counter calibration: profiles/r2_valu_busy_calibrated.json)")
+                            "the ideal issue cycles of the loop's instruction mix (2 / 4 / 8 per class) against the cycles "
+                            "measured with the shader clock of THIS run (DESIGN.md 4.1)")
         if args.workload in ("nucleon", "stress"):
             # HBM bytes per launch of this workload's kernel from its committed PMC passes (not measured in this run)
             prof = {"nucleon": "r2_pmc_nucleon_kernel.json", "stress": "r2_pmc_stress_kernel.json"}[args.workload]
@@ -499,9 +523,27 @@ def main(argv=None):
                                               "workload, tools/gpu_profile.sh; not measured in this run)")
             except (OSError, KeyError, ValueError):
                 pass
+        if args.workload == "stress" and args.full:
+            # the HBM-heavy form of configs[4]: 268 B per chain-sweep; the line's roofline is the HBM one
+            # (the VALU figures stay beside it: the kernel overlaps its stores with 64 proposals per chain-sweep)
+            gbps = wl.algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+            roof.update({"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                         "valu": {"achieved_TFLOPs": achieved, "peak_TFLOPs": VALU_PEAK_TFLOPS, "frac": achieved / VALU_PEAK_TFLOPS}})
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_stress_full_kernel.json")))
+                if pm["derived"].get("algorithmic_bytes_per_launch") == wl.algorithmic_bytes:
+                    roof["traffic"] = pm["derived"]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = ("profiles/r3_pmc_stress_full_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                              "of this workload, tools/gpu_profile.sh; not measured in this run)")
+            except (OSError, KeyError, ValueError):
+                pass
         if args.workload == "nucleon":
             roof["note"] = ("FP32 VALU-issue-bound like the chain kernel; 24 + 6 (Kahan r^2) algorithmic flop per proposal. "
                             "kernel_ms brackets xs_chain_kernel + the two row-mean kernels of the launch")
+        elif args.workload == "stress" and args.full:
+            roof["note"] = ("configs[4] with every sample written back: 12 + 4 x 64 B of HBM traffic per chain-sweep (observable, lag "
+                            "ring read + write, the 64-D state) + state load/store per launch, against 8 TB/s; `valu` gives the "
+                            "22-flop-per-update figure of the same launch")
         elif args.workload == "stress":
             roof["note"] = ("BASELINE configs[4] calls this the HBM-bound path; measured it is VALU-issue-bound: 64 proposals "
                             "per 12 B of HBM traffic per chain-sweep. `hbm` gives the algorithmic bytes (12 B per chain-sweep + "
@@ -539,13 +581,6 @@ def main(argv=None):
                                  "frac_of_ideal_issue": mix["issue_cycles_per_wave_proposal_ideal"] / cyc,
                                  "valu_insts_per_proposal": mix["valu_insts_per_proposal"],
                                  "isa_mix_source": f"profiles/{mix_file} (static, tools/isa_mix.py; 2 / 4 / 8 cycles per class)"})
-                    cal = json.load(open(os.path.join(ROOT, "profiles", "r2_valu_busy_calibrated.json")))
-                    for k, e in cal["kernels"].items():
-                        if k.startswith("chain:") and "static_mix" in e:
-                            c = e["static_mix"]["calibrated_issue_cycles_per_wave_proposal"]
-                            valu.update({"calibrated_issue_cycles": c, "frac_of_calibrated_issue": c / cyc,
-                                         "calibration_source": "profiles/r2_valu_busy_calibrated.json (per-instruction issue costs "
-                                                               "from pure-instruction loops under rocprofv3 counters)"})
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"]["valu_issue"] = valu
@@ -561,18 +596,26 @@ def main(argv=None):
         e2.run(512, n_lags=0)
         e2.run(256, window_start=True, n_lags=L.MAX_LAGS)
         torch.cuda.synchronize()
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ea.record()
-        lag_sweeps = 4096   # the launch length of a step-size study (C2: 10^4); a launch has ~60 steps' worth of fixed cost
-        e2.run(lag_sweeps, window_start=True, n_lags=L.MAX_LAGS)
-        eb.record()
-        torch.cuda.synchronize()
+        rates = {}
+        for lag_sweeps in (1024, 4096):   # a step-size study's launches are 10^3 - 10^4 sweeps (C2: 10^4)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            e2.run(lag_sweeps, window_start=True, n_lags=L.MAX_LAGS)
+            eb.record()
+            torch.cuda.synchronize()
+            rates[lag_sweeps] = sub * args.coords * lag_sweeps / (ea.elapsed_time(eb) * 1e-3)
         tau = e2.summary()[0]["tau_int"]
         if out is not None:
-            out["ess_per_sec"] = value / tau
             out["tau_int"] = tau
-            out["lag49_proposals_per_sec_per_gpu"] = sub * args.coords * lag_sweeps / (ea.elapsed_time(eb) * 1e-3)
-            out["lag49_sweeps_per_launch"] = lag_sweeps
+            # two readings of "ESS/sec": the headline kernel's rate (mean / variance / acceptance only) over tau_int, and the
+            # rate of the kernel that MEASURES tau_int (all 49 lag products of every chain, on the matrix cores) over it
+            out["ess_per_sec"] = value / tau
+            out["lag49_proposals_per_sec_per_gpu"] = rates[4096]
+            out["lag49_sweeps_per_launch"] = 4096
+            out["lag49_proposals_per_sec_per_gpu_1024_sweeps"] = rates[1024]
+            out["ess_per_sec_lag49_kernel"] = n_gpus * rates[4096] / tau
+            out["lag49_kernel"] = "mcmc::chain_lag_kernel (v_mfma_f32_16x16x32_f16)" if os.environ.get("MCMC_LAG_MFMA", "1") != "0" \
+                else "mcmc::chain_kernel<NLAG=49> (VALU)"
     if rank == 0 and n_gpus == 1 and args.workload == "chain" and not args.no_secondary:
         out["secondary"] = secondary(dev)
         p7 = philox7_rate(args)

@@ -2,6 +2,8 @@
 // selection, launch; and the host finalisation of the statistics vector with
 // the exact formulas of stepsize/include/statistics.hpp:6-57.
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -18,7 +20,36 @@ int chain_dispatch_kind_2(const mcmc_chain_args *, const ChainParams &, dim3, hi
 int chain_dispatch_kind_3(const mcmc_chain_args *, const ChainParams &, dim3, hipStream_t);
 } // namespace mcmc
 
+namespace mcmc {
+int g_lag_mfma = -1; // MCMC_LAG_MFMA: 0 = lag products on the VALU (chain_kernel), otherwise chain_lag_kernel; -1 = not read yet
+}
+
 namespace {
+
+bool lag_mfma_enabled()
+{
+    if (g_lag_mfma < 0) {
+        const char *v = std::getenv("MCMC_LAG_MFMA");
+        g_lag_mfma = v && v[0] == '0' ? 0 : 1;
+    }
+    return g_lag_mfma != 0;
+}
+
+// chain_lag_kernel stores y s as two f16 halves: s = the power of two that maps the farthest |x - center| a chain of this
+// target can reach (40 diffuseness lengths / 12 standard deviations beyond the bulk, plus 8 proposal widths) to <= 2^15.
+// Samples beyond it (a chain started far away) saturate at 65000 / s.
+float lag_scale_for(const mcmc_chain_args *a)
+{
+    const mcmc_target &t = a->target;
+    double reach = t.kind == MCMC_TARGET_WS || t.kind == MCMC_TARGET_R2WS ? std::fabs((double)t.p0) + 40.0 * std::fabs((double)t.p1)
+                                                                             : 12.0 * std::sqrt(std::fabs((double)t.p0));
+    reach += std::fabs(a->center) + 8.0 * std::fabs(a->step_size);
+    if (!(reach > 0.0) || !std::isfinite(reach)) reach = 1.0;
+    int e = 15 - (int)std::ceil(std::log2(reach));
+    if (e > 100) e = 100;
+    if (e < -100) e = -100;
+    return std::ldexp(1.0f, e);
+}
 
 uint32_t chain_grid_x(uint64_t n_chains)
 {
@@ -79,6 +110,8 @@ int chain_launch(const mcmc_chain_args *a, void *workspace, size_t workspace_byt
     p.inj_uniforms = a->inj_uniforms;
     p.accept_bits = a->accept_bits;
     p.stamps = stamps;
+    p.lag_mfma = a->precision == 32 && a->n_lags > 0 && lag_mfma_enabled();
+    p.lag_scale = lag_scale_for(a);
 
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(chain_grid_x(a->n_chains), a->n_coords);

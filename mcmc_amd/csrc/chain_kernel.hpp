@@ -39,6 +39,8 @@ struct ChainParams {
     const void *inj_normals;
     const void *inj_uniforms;
     uint8_t *accept_bits;
+    float lag_scale;  // chain_lag_kernel: power of two that maps |x - center| into f16's normal range
+    int lag_mfma;     // FP32 with lags: 1 = chain_lag_kernel (lag products on the matrix cores), 0 = the VALU form below
     uint64_t *stamps; // STAMP instantiation only: [n_coords][gridDim.x][2] = shader cycles, 100 MHz ticks of the block's tile loop
 };
 

@@ -22,7 +22,8 @@ int launch_sab_mode_4(const mcmc_xs_args *, const XsParams &, int G, size_t lds,
 } // namespace mcmc
 
 namespace mcmc {
-extern int g_mvn_reg; // mvn.hip
+extern int g_mvn_reg;  // mvn.hip
+extern int g_lag_mfma; // chain.hip
 }
 
 namespace {
@@ -289,8 +290,12 @@ extern "C" int mcmc_set_option(const char *name, const char *value)
         g_mvn_reg = value && value[0] == '0' ? 0 : value && value[0] == '1' ? 1 : -1;
         return MCMC_OK;
     }
+    if (std::strcmp(name, "MCMC_LAG_MFMA") == 0) { // FP32 chains with lags: 0 = lag products on the VALU, else the matrix cores
+        g_lag_mfma = value && value[0] == '0' ? 0 : 1;
+        return MCMC_OK;
+    }
     if (std::strcmp(name, "MCMC_SAB_CULL") && std::strcmp(name, "MCMC_SAB_SMALL") && std::strcmp(name, "MCMC_SAB_PLAN"))
-        return set_error(MCMC_EINVAL, "unknown option (MCMC_SAB_CULL, MCMC_SAB_SMALL, MCMC_SAB_PLAN, MCMC_MVN_REG)");
+        return set_error(MCMC_EINVAL, "unknown option (MCMC_SAB_CULL, MCMC_SAB_SMALL, MCMC_SAB_PLAN, MCMC_MVN_REG, MCMC_LAG_MFMA)");
     (void)sab_options(); // the environment first, so that this call wins
     std::lock_guard<std::mutex> lock(opt_mutex);
     parse_option(opt_state, name, value);

@@ -237,7 +237,13 @@ def test_split_launches_and_chain_partition_are_invariant(dev):
     t1 = h1.run(n).clone()
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([h0.state, h1.state], dim=1), a.state)
-    np.testing.assert_allclose((t0 + t1).cpu().numpy(), sa.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    # sums, accepts, head and tail sums: per-chain FP64 -- equal to FP64 rounding.  The FP32 lag products are pooled per
+    # wavefront of 64 chains in FP32 tiles (chain_lag_kernel.hpp): a partition at chain 500 regroups the chains, so they
+    # agree to FP32 accumulation rounding (partitions at multiples of 64 chains: test_gpu_multi.py, FP64 rounding)
+    tt, ss = (t0 + t1).cpu().numpy(), sa.cpu().numpy()
+    np.testing.assert_allclose(tt[:, :3], ss[:, :3], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(tt[:, core:], ss[:, core:], rtol=0, atol=2e-6 * N)   # row sums of the (h, l) halves, FP32 tiles
+    np.testing.assert_allclose(tt[:, 3:core], ss[:, 3:core], rtol=0, atol=2e-6 * N * n)
 
 
 @pytest.mark.parametrize("mode", ["recip_fast", "nodiv_fast", "log_fast", "cross_fast", "recip_precise"])
