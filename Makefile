@@ -94,14 +94,14 @@ tools/bin/dist_probe: tools/dist_probe.hip include/mcmc_distributions.h
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Iinclude -o $@ $<
 
 # VALU issue-rate microbenchmark (calibrates the cycle model of tools/isa_mix.py)
-ubench: tools/bin/ubench tools/bin/ubench2 tools/bin/ubench3 tools/bin/ubench_cal
+ubench: tools/bin/ubench tools/bin/ubench2 tools/bin/ubench3 tools/bin/ubench_cal tools/bin/ubench_mfma
 tools/bin/%: tools/%.hip
 	@mkdir -p tools/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<
 
 # A/B builds of the lag kernel (tools/lag49_probe.py with MCMC_HIP_LIB=tools/bin/libmcmc_hip_lagab.so): only the r^2
-# Woods-Saxon chain kernels are rebuilt, with LAGAB_FLAGS (e.g. -DMCMC_LAGM_BLOCKS_PER_CU=4)
-LAGAB_FLAGS ?= -DMCMC_LAGM_BLOCKS_PER_CU=4
+# Woods-Saxon chain kernels are rebuilt, with LAGAB_FLAGS (e.g. -DMCMC_LAG_PHASES: prologue / epilogue cycles through tools/dbg/lag_phases.py)
+LAGAB_FLAGS ?= -DMCMC_LAG_PHASES
 lagab: $(LIB)
 	mkdir -p build/lagab tools/bin
 	$(HIPCC) $(HIPFLAGS) -fno-slp-vectorize -DMCMC_KIND=1 $(LAGAB_FLAGS) -c $(CSRC)/chain_kind.hip -o build/lagab/chain_kind_1.o

@@ -127,7 +127,9 @@ int mcmc_chain_run(const mcmc_chain_args *a, void *stream);
  * allocation).  The block partials go to a device array inside the library (MCMC_CHAIN_NOALLOC_MAX_BYTES, held by
  * every GPU the library runs on until the process ends); a->workspace / workspace_bytes are ignored.  Arguments
  * whose mcmc_chain_workspace_bytes() exceeds that size are rejected with MCMC_ENOMEM.  Results are identical to
- * mcmc_chain_run.  All calls on one GPU share the array: calls that overlap on one GPU (different streams or
+ * mcmc_chain_run.  The array's device address is looked up (hipGetSymbolAddress) once per device, by the first
+ * mcmc_chain_run OR mcmc_chain_run_noalloc call on that device: make one such call on every device you use BEFORE
+ * the capture / no-allocation region, and calls inside it do nothing but launch.  All calls on one GPU share the array: calls that overlap on one GPU (different streams or
  * threads) race; calls on one stream are ordered and safe.                                                    */
 #define MCMC_CHAIN_NOALLOC_MAX_BYTES (8u << 20)
 int mcmc_chain_run_noalloc(const mcmc_chain_args *a, void *stream);

@@ -2,12 +2,14 @@
 // selection, launch; and the host finalisation of the statistics vector with
 // the exact formulas of stepsize/include/statistics.hpp:6-57.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
 
-#include "chain_kernel.hpp"
+#include "chain_lag_kernel.hpp"
 #include "host_common.hpp"
 
 using namespace mcmc;
@@ -114,7 +116,9 @@ int chain_launch(const mcmc_chain_args *a, void *workspace, size_t workspace_byt
     p.lag_scale = lag_scale_for(a);
 
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(chain_grid_x(a->n_chains), a->n_coords);
+    // FP32 with lags: 768-thread workgroups of chain_lag_kernel (never more of them than the 256-thread tiles the
+    // workspace is sized for)
+    const dim3 grid(p.lag_mfma ? lag_grid_x(a->n_chains) : chain_grid_x(a->n_chains), a->n_coords);
     int rc;
     switch (a->target.kind) {
     case MCMC_TARGET_WS: rc = chain_dispatch_kind_0(a, p, grid, s); break;
@@ -131,12 +135,6 @@ int chain_launch(const mcmc_chain_args *a, void *workspace, size_t workspace_byt
 }
 } // namespace
 
-extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
-{
-    if (!a) return set_error(MCMC_EINVAL, "null args");
-    return chain_launch(a, a->workspace, a->workspace_bytes, nullptr, stream);
-}
-
 // ---------------------------------------------------------------------
 // mcmc_chain_run for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid
 // hipMalloc): the block partials go to a file-scope device array instead of a caller workspace.  Every GPU the
@@ -147,24 +145,38 @@ constexpr size_t CHAIN_SCRATCH_BYTES = MCMC_CHAIN_NOALLOC_MAX_BYTES;
 static __device__ __align__(256) unsigned char chain_scratch[CHAIN_SCRATCH_BYTES];
 constexpr int SCRATCH_MAX_DEVICES = 64;
 std::mutex scratch_mutex;
-void *scratch_ptr[SCRATCH_MAX_DEVICES]; // per device; nullptr = not looked up yet
+std::atomic<void *> scratch_ptr[SCRATCH_MAX_DEVICES]; // per device; nullptr = not looked up yet
 
 int chain_scratch_for_current_device(void **out)
 {
     int dev = -1;
     MCMC_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) return set_error(MCMC_EINVAL, "device ordinal beyond the scratch table");
-    std::lock_guard<std::mutex> lock(scratch_mutex);
-    if (scratch_ptr[dev] == nullptr) {
-        void *ptr = nullptr;
-        MCMC_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(chain_scratch)));
-        if (ptr == nullptr) return set_error(MCMC_EINVAL, "hipGetSymbolAddress returned a null scratch address");
-        scratch_ptr[dev] = ptr;
+    void *ptr = scratch_ptr[dev].load(std::memory_order_acquire);
+    if (ptr == nullptr) {
+        std::lock_guard<std::mutex> lock(scratch_mutex);
+        ptr = scratch_ptr[dev].load(std::memory_order_relaxed);
+        if (ptr == nullptr) {
+            MCMC_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(chain_scratch)));
+            if (ptr == nullptr) return set_error(MCMC_EINVAL, "hipGetSymbolAddress returned a null scratch address");
+            scratch_ptr[dev].store(ptr, std::memory_order_release);
+        }
     }
-    *out = scratch_ptr[dev];
+    *out = ptr;
     return MCMC_OK;
 }
 } // namespace
+
+extern "C" int mcmc_chain_run(const mcmc_chain_args *a, void *stream)
+{
+    if (!a) return set_error(MCMC_EINVAL, "null args");
+    // Resolve the no-allocation entry point's scratch address for this device now (once per device; afterwards one relaxed
+    // load): a caller that has run ANY chain launch on a device can enter a capture / no-allocation region and call
+    // mcmc_chain_run_noalloc there without that call doing anything but launching.  Failure here is not this call's error.
+    void *unused = nullptr;
+    (void)chain_scratch_for_current_device(&unused);
+    return chain_launch(a, a->workspace, a->workspace_bytes, nullptr, stream);
+}
 
 extern "C" int mcmc_chain_run_noalloc(const mcmc_chain_args *a, void *stream)
 {
@@ -201,6 +213,12 @@ extern "C" int mcmc_chain_clock_probe(const mcmc_chain_args *a, double *clock_gh
     (void)hipFree(d_stamps);
     if (rc != MCMC_OK) return rc;
     if (e != hipSuccess) return set_hip_error(e, __FILE__, __LINE__);
+    if (const char *dump = std::getenv("MCMC_STAMP_DUMP")) { // development: the raw stamps, two 64-bit words per workgroup
+        if (FILE *f = std::fopen(dump, "wb")) {
+            std::fwrite(h.data(), sizeof(uint64_t), h.size(), f);
+            std::fclose(f);
+        }
+    }
     std::vector<double> ratio;
     for (size_t b = 0; b < nblk; ++b)
         if (h[2 * b + 1] > 0) ratio.push_back((double)h[2 * b] / (double)h[2 * b + 1]);

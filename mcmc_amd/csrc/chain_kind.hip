@@ -1,5 +1,7 @@
 // chain_kind.hip -- kernel instantiations of chain_kernel.hpp for ONE target
 // kind (compiled four times with -DMCMC_KIND=0..3 so the build parallelises).
+#include <atomic>
+
 #include "chain_lag_kernel.hpp"
 #include "host_common.hpp"
 
@@ -13,16 +15,20 @@ namespace {
 
 constexpr int NLAG_MAX = MCMC_MAX_LAGS;
 
+template <auto Kernel>
+void launch_lag(const ChainParams &p, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(Kernel, grid, dim3(LAG_THREADS), 0, s, p);
+}
+
 // 49 lags: FP32 takes chain_lag_kernel (lag products on the matrix cores) unless MCMC_LAG_MFMA=0 asks for the VALU form
 template <typename Real, int KIND, int RULE, int MATH, bool INJ>
 void launch_with_lags(const ChainParams &p, dim3 grid, hipStream_t s)
 {
     if constexpr (sizeof(Real) == 4) {
-        if (p.lag_mfma) {
-            if (p.samples != nullptr || p.accept_bits != nullptr)
-                hipLaunchKernelGGL((chain_lag_kernel<KIND, RULE, MATH, INJ, 1>), grid, dim3(CHAIN_BLOCK), 0, s, p);
-            else
-                hipLaunchKernelGGL((chain_lag_kernel<KIND, RULE, MATH, INJ, 0>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+        if (p.lag_mfma) { // `grid` is lag_grid_x(n_chains) x n_coords (chain.hip)
+            if (p.samples != nullptr || p.accept_bits != nullptr) launch_lag<chain_lag_kernel<KIND, RULE, MATH, INJ, 1>>(p, grid, s);
+            else launch_lag<chain_lag_kernel<KIND, RULE, MATH, INJ, 0>>(p, grid, s);
             return;
         }
     }
@@ -49,11 +55,11 @@ int pick_stamped(const mcmc_chain_args *a, const ChainParams &p, dim3 grid, hipS
         return set_error(MCMC_EINVAL, "the clock probe runs the FP32 FAST-math Philox kernel without write-back");
     if (a->accept_rule == MCMC_ACCEPT_CROSS) {
         if (p.n_lags == 0) launch_chain_stamped<KIND, MCMC_ACCEPT_CROSS, 0>(p, grid, s);
-        else if (p.lag_mfma) hipLaunchKernelGGL((chain_lag_kernel<KIND, MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, false, 0, true>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+        else if (p.lag_mfma) launch_lag<chain_lag_kernel<KIND, MCMC_ACCEPT_CROSS, MCMC_MATH_FAST, false, 0, true>>(p, grid, s);
         else launch_chain_stamped<KIND, MCMC_ACCEPT_CROSS, NLAG_MAX>(p, grid, s);
     } else if (a->accept_rule == MCMC_ACCEPT_RECIP) {
         if (p.n_lags == 0) launch_chain_stamped<KIND, MCMC_ACCEPT_RECIP, 0>(p, grid, s);
-        else if (p.lag_mfma) hipLaunchKernelGGL((chain_lag_kernel<KIND, MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, false, 0, true>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+        else if (p.lag_mfma) launch_lag<chain_lag_kernel<KIND, MCMC_ACCEPT_RECIP, MCMC_MATH_FAST, false, 0, true>>(p, grid, s);
         else launch_chain_stamped<KIND, MCMC_ACCEPT_RECIP, NLAG_MAX>(p, grid, s);
     } else {
         return set_error(MCMC_EINVAL, "the clock probe is instantiated for MCMC_ACCEPT_CROSS and MCMC_ACCEPT_RECIP");

@@ -18,11 +18,14 @@
 //     registers (48 VGPRs); shifting the windows by one sample makes FOUR tiles cover the lags 1..49 exactly (every
 //     lag has 16 entries per block; entries with lag < 1 or > 49 are never read);
 //   * the tiles accumulate in f32 over 64 blocks (1024 steps: 2048 MFMA accumulations per entry), then their
-//     diagonals are summed through LDS in FP64 (lane k-1 adds the 16 entries of lag k in a fixed order).
-// Per step that is 3 + 1 (ds_write) vector instructions and 2 MFMAs (8 issue cycles each, on the otherwise idle
-// matrix pipe) in place of 49 FMAs.  Head / tail sums, the ring carried between launches and every other statistic
-// are those of chain_kernel.hpp; the ring holds exact FP32 samples, so a window split into launches sees the same
-// (h, l) pairs as one launch.
+//     diagonals are summed through LDS in FP64 (lane k-1 adds the 16 entries of lag k in a fixed order);
+//   * the 32 MFMAs of a block are spread over the 16 steps of the NEXT block, two after every step (the block's rows
+//     stay in the other half of the ring meanwhile): a wave's matrix instructions then sit between its own vector
+//     instructions.  As one burst of 32 per block they cost 194 cycles per wave-step, spread out 186 - 189.
+// Per step that is 5 + 1 (ds_write) vector instructions and 2 MFMAs in place of 49 FMAs.  Head / tail sums are MFMA
+// row sums (A . 1) of the four blocks at either end of a window; the ring carried between launches and every other
+// statistic are those of chain_kernel.hpp; the ring holds exact FP32 samples, so a window split into launches sees the
+// same (h, l) pairs as one launch.
 #pragma once
 #include "chain_kernel.hpp"
 
@@ -42,9 +45,20 @@ constexpr int LAG_PITCH = 68;
 constexpr int LAG_FLUSH = 64; // blocks between folds of the f32 tiles into FP64
 static_assert(16 * (LAG_TILES - 1) + 1 + 15 >= MCMC_MAX_LAGS, "the tiles must reach the largest lag");
 
-#ifndef MCMC_LAGM_BLOCKS_PER_CU
-#define MCMC_LAGM_BLOCKS_PER_CU 3
-#endif
+// Workgroup: 256 threads, three workgroups per CU (168 VGPRs).  Measured on MI355X (tools/ubench_mfma.hip,
+// profiles/r3_ubench_mfma.jsonl): matrix and vector instructions of DIFFERENT waves of a SIMD do not overlap here (a
+// burst of 32 MFMAs + 256 v_fma per wave costs their sum), so more waves do not hide the MFMAs.  A 768-thread workgroup
+// (the SIMD's three waves entering every block's MFMAs together behind a barrier) measured slower: 246 cycles.
+constexpr int LAG_THREADS = CHAIN_BLOCK;
+constexpr int LAG_WAVES = LAG_THREADS / 64;
+constexpr int LAG_STATS_MAX = 3 + 3 * MCMC_MAX_LAGS;
+
+// workgroups of a launch: one tile of LAG_THREADS chains each, grid-strided beyond 2048 (the partials buffer is sized for <= 2048)
+__host__ __device__ inline uint32_t lag_grid_x(uint64_t n_chains)
+{
+    const uint64_t tiles = (n_chains + LAG_THREADS - 1) / LAG_THREADS;
+    return (uint32_t)(tiles < 2048 ? tiles : 2048);
+}
 
 // y s -> (h, l) as two f16 in one dword (h low).  |y s| is clamped below f16's largest value: a chain started far from
 // the target cannot poison the tiles with inf * 0.
@@ -67,11 +81,11 @@ __device__ __forceinline__ void lag_wave_fence()
 }
 
 template <int KIND, int RULE, int MATH, bool INJ, int STORE, bool STAMP = false>
-__global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_lag_kernel(const ChainParams p)
+__global__ __launch_bounds__(LAG_THREADS, 3) void chain_lag_kernel(const ChainParams p)
 {
     constexpr int NL = MCMC_MAX_LAGS;
-    __shared__ double sred[CHAIN_WAVES][3 + 3 * NL];
-    __shared__ __attribute__((aligned(16))) uint32_t ybuf[CHAIN_WAVES][LAG_ROWS * LAG_PITCH];
+    __shared__ double sred[LAG_WAVES][LAG_STATS_MAX];
+    __shared__ __attribute__((aligned(16))) uint32_t ybuf[LAG_WAVES][LAG_ROWS * LAG_PITCH];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -80,7 +94,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
     const int len = 3 + 3 * (int)p.n_lags;
     const int L = (int)p.n_lags;
 
-    for (int i = tid; i < CHAIN_WAVES * (3 + 3 * NL); i += CHAIN_BLOCK) (&sred[0][0])[i] = 0.0;
+    for (int i = tid; i < LAG_WAVES * LAG_STATS_MAX; i += LAG_THREADS) (&sred[0][0])[i] = 0.0;
     __syncthreads();
 
     constexpr bool PRESCALED = !INJ && MATH == MCMC_MATH_FAST;
@@ -112,10 +126,20 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
         stamp_r = __builtin_amdgcn_s_memrealtime();
     }
 
-    for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-        const uint64_t chain = (uint64_t)tile * CHAIN_BLOCK + tid;
+    const uint32_t n_tiles = (uint32_t)((nc + LAG_THREADS - 1) / LAG_THREADS);
+#ifdef MCMC_LAG_PHASES // development build (make lagab): cycles before and after the step loop, summed over the tiles
+    uint64_t ph_pro = 0, ph_epi = 0, ph_mark = 0;
+#endif
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#ifdef MCMC_LAG_PHASES
+        if constexpr (STAMP) ph_mark = __builtin_amdgcn_s_memtime();
+#endif
+        const uint64_t chain = (uint64_t)tile * LAG_THREADS + tid;
         const bool valid = chain < nc;
-        if ((uint64_t)tile * CHAIN_BLOCK + (uint64_t)wave * 64 >= nc) continue; // see chain_kernel.hpp
+        // A wave that lies wholly past the last chain (last tile only) still walks through the loop -- every wave of the
+        // workgroup meets the same barriers -- but touches no memory of the chains: it steps a private copy of the last
+        // chain and stores nothing (chain_kernel.hpp explains why it must not write that chain's slots).
+        const bool wave_live = (uint64_t)tile * LAG_THREADS + (uint64_t)wave * 64 < nc;
         const uint64_t ch = valid ? chain : nc - 1;
         const uint64_t gid = p.chain_offset + ch;
         float *state = (float *)p.state + (uint64_t)coord * nc + ch;
@@ -194,44 +218,71 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
         const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
         uint64_t wacc = 0;
 
-        // fold the f32 tiles into the FP64 lag sums: diagonals through LDS (the ring half that block J does not use)
-        auto flush_tiles = [&](uint64_t J) __attribute__((always_inline)) {
-            float *st = reinterpret_cast<float *>(yw + (16 * (int)((J + 1) & 1)) * LAG_PITCH); // 16 rows >= the 1024 floats of four tiles
-            lag_wave_fence();
+        // Fold the f32 tiles into the FP64 lag sums: their diagonals, through LDS.  Staging = rows 0..14 of the ring half
+        // `free_half` (0 / 16), whose block has been consumed -- its row 15 may still be the row before a pending block.
+        // Two tiles (512 floats) per pass.
+        auto flush_tiles = [&](int free_half) __attribute__((always_inline)) {
+            float *st = reinterpret_cast<float *>(yw + free_half * LAG_PITCH);
+            // The staging addresses depend on the lane alone; left to itself the compiler computes all 32 of them (and 32
+            // lane masks) once per kernel, spills them, and reloads them here one by one behind a branch each -- 32
+            // dependent trips to scratch memory per fold (measured: 15k - 24k cycles per tile).  An opaque copy of the lane
+            // keeps the arithmetic here, and the loop is branch-free.
+            int k1 = lane;
+            asm volatile("" : "+v"(k1));
+            double acc = 0.0;
 #pragma unroll
-            for (int d = 0; d < LAG_TILES; ++d)
+            for (int pass = 0; pass < 2; ++pass) {
+                lag_wave_fence();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[((d * 16 + 4 * g4 + r) << 4) + r16] = C[d][r]; // C[i = 4 g + r][j = lane % 16]
-            lag_wave_fence();
-            if (lane < NL) {
-                double acc = 0.0;
+                for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[((dd * 16 + 4 * g4 + r) << 4) + r16] = C[2 * pass + dd][r]; // C[i = 4 g + r][j = lane % 16]
+                lag_wave_fence();
 #pragma unroll
                 for (int i = 0; i < LAG_BLK; ++i) {
-                    const int v = lane - i;              // (k - 1) - i with k = lane + 1
-                    const int d = (v + 15) >> 4;         // the tile that holds lag k for row i
+                    const int v = k1 - i;                // (k - 1) - i with k = lane + 1
+                    const int d = (v + 15) >> 4;         // the tile that holds lag k for row i (0 .. 3 for k <= 49)
                     const int j = 16 * d - v;            // its column
-                    acc += (double)st[((d * 16 + i) << 4) + j];
+                    const bool use = (d >> 1) == pass && k1 < NL;
+                    const float val = st[use ? ((((d & 1) * 16 + i) << 4) + j) : 0];
+                    acc += use ? (double)val : 0.0;
                 }
-                if (lane < L) sred[wave][3 + lane] += acc * inv_s2;
             }
+            if (k1 < L && k1 < NL) sred[wave][3 + k1] += acc * inv_s2;
             lag_wave_fence();
 #pragma unroll
             for (int d = 0; d < LAG_TILES; ++d) C[d] = lag_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             blocks_since_flush = 0;
         };
 
-        // Block J = steps [16 J, 16 J + 16) is complete in the LDS ring (rows outside [lo, hi) belong to another launch or
-        // do not exist: they are history / stale as S rows -- where only lags < 1 can reach them -- and zero as A rows).
-        auto lag_block = [&](uint64_t J, int lo, int hi, bool want_rows) __attribute__((always_inline)) {
+        // Row sums of block J (the sum over the wave's chains of every row, A . 1) -> the head sums A_i and tail sums Z_j
+        const _Float16 one_h = (_Float16)1.0f;
+        const lag_half8 ones = {one_h, one_h, one_h, one_h, one_h, one_h, one_h, one_h};
+        auto add_rows = [&](uint64_t J, const lag_f32x4 &rs) __attribute__((always_inline)) {
+            if (r16 == 0) { // column 0: lane 16 g holds the rows 4 g .. 4 g + 3
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t t = (J << 4) + (uint64_t)(4 * g4 + r);
+                    const double v = (double)rs[r] * inv_s;
+                    if (t >= t_begin && t < head_end) sred[wave][3 + L + (int)(t - t_begin)] += v;
+                    if (t >= tail_begin && t < t_end) sred[wave][3 + 2 * L + (int)(t_end - 1 - t)] += v;
+                }
+            }
+        };
+        auto wants_rows = [&](uint64_t J) __attribute__((always_inline)) { return (J << 4) < head_end || ((J + 1) << 4) > tail_begin; };
+
+        // Block J = steps [16 J, 16 J + 16) is complete in the LDS ring: its products.  Rows outside [lo, hi) (first / last
+        // block of a launch) belong to another launch or do not exist: history / stale as S rows -- where only lags < 1 can
+        // reach them -- and zero as A rows.
+        auto lag_block = [&](uint64_t J, int lo, int hi) __attribute__((always_inline)) {
             lag_wave_fence();
             const int half = 16 * (int)(J & 1);
             const uint32_t *rowA = yw + (half + r16) * LAG_PITCH + 4 * g4;
             const uint32_t *rowS = yw + ((half + r16 + 31) & 31) * LAG_PITCH + 4 * g4;
             lag_half8 a[4], s0[4];
-            // First / last block of the launch (not the hot path).  Rows at or after the launch's end hold whatever the
-            // ring held before (zeros, or the f32 staging of an earlier fold: any bit pattern, NaN included) and are
-            // cleared BEFORE the window is read; rows before its start hold the history, which the window needs, and are
-            // cleared after it is read, so that they are zeros as A rows.
+            // Rows at or after the launch's end hold whatever the ring held before (zeros, or the f32 staging of an earlier
+            // fold: any bit pattern, NaN included) and are cleared BEFORE the window is read; rows before its start hold the
+            // history, which the window needs, and are cleared after it is read, so that they are zeros as A rows.
             if (hi < LAG_BLK) {
 #pragma unroll 1
                 for (int row = hi; row < LAG_BLK; ++row) yw[(half + row) * LAG_PITCH + lane] = 0u;
@@ -247,48 +298,41 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const lag_half8 *>(rowA + 16 * q);
-            if (want_rows) {
-                // Blocks that hold head or tail steps: the sum over the wave's chains of every row, A . 1 (all K slots 1.0:
-                // h + l of every chain), for the head sums A_i and the tail sums Z_j -- no per-step wave reduction.
-                const _Float16 one = (_Float16)1.0f;
-                const lag_half8 ones = {one, one, one, one, one, one, one, one};
+            if (wants_rows(J)) { // blocks that hold head or tail steps: A . 1, the sum over the wave's chains of every row
                 lag_f32x4 rs = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) rs = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q], ones, rs, 0, 0, 0);
-                if (r16 == 0) { // column 0: lane 16 g holds the rows 4 g .. 4 g + 3
+                add_rows(J, rs);
+            }
+            // A . S gives h h' + l l', rot16(A) . S gives l h' + h l'.  Four MFMAs in a row on one accumulator (the
+            // accumulate-forwarding path: 10.8 instead of 12.3 cycles per MFMA, tools/ubench_mfma.hip).
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint64_t t = (J << 4) + (uint64_t)(4 * g4 + r);
-                        const double v = (double)rs[r] * inv_s;
-                        if (t >= t_begin && t < head_end) sred[wave][3 + L + (int)(t - t_begin)] += v;
-                        if (t >= tail_begin && t < t_end) sred[wave][3 + 2 * L + (int)(t_end - 1 - t)] += v;
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) C[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q], s0[q], C[0], 0, 0, 0);
+#pragma unroll
+                for (int d = 1; d < LAG_TILES; ++d)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) C[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q], S[d - 1][q], C[d], 0, 0, 0);
+                if (pass == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint4 u = __builtin_bit_cast(uint4, a[q]);
+                        u.x = __builtin_amdgcn_alignbit(u.x, u.x, 16); // (h, l) -> (l, h)
+                        u.y = __builtin_amdgcn_alignbit(u.y, u.y, 16);
+                        u.z = __builtin_amdgcn_alignbit(u.z, u.z, 16);
+                        u.w = __builtin_amdgcn_alignbit(u.w, u.w, 16);
+                        a[q] = __builtin_bit_cast(lag_half8, u);
                     }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint4 u = __builtin_bit_cast(uint4, a[q]);
-                u.x = __builtin_amdgcn_alignbit(u.x, u.x, 16); // (h, l) -> (l, h)
-                u.y = __builtin_amdgcn_alignbit(u.y, u.y, 16);
-                u.z = __builtin_amdgcn_alignbit(u.z, u.z, 16);
-                u.w = __builtin_amdgcn_alignbit(u.w, u.w, 16);
-                const lag_half8 asw = __builtin_bit_cast(lag_half8, u);
-                C[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q], s0[q], C[0], 0, 0, 0);
-                C[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q], S[0][q], C[1], 0, 0, 0);
-                C[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q], S[1][q], C[2], 0, 0, 0);
-                C[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[q], S[2][q], C[3], 0, 0, 0);
-                C[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(asw, s0[q], C[0], 0, 0, 0);
-                C[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(asw, S[0][q], C[1], 0, 0, 0);
-                C[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(asw, S[1][q], C[2], 0, 0, 0);
-                C[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(asw, S[2][q], C[3], 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q) { // the windows move on by one block
                 S[2][q] = S[1][q];
                 S[1][q] = S[0][q];
                 S[0][q] = s0[q];
             }
-            if (++blocks_since_flush >= LAG_FLUSH) flush_tiles(J);
+            if (++blocks_since_flush >= LAG_FLUSH) flush_tiles(16 - half);
         };
 
         // One sweep of this chain, global step t; yrow = the LDS ring row of t (+ lane).
@@ -307,12 +351,12 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
             const float ys = __builtin_fmaf(x, lscale, ncs); // (x - center) s: one rounding, the scaling is exact
             s1 += ys;
             s2 = __builtin_fmaf(ys, ys, s2);
-#if !defined(MCMC_LAG_EXPERIMENT) || MCMC_LAG_EXPERIMENT < 2
             *yrow = lag_pack_scaled(ys);
-#endif
             if constexpr (STORE == 1) {
-                if (p.samples != nullptr) __builtin_nontemporal_store(x, (float *)p.samples + slot);
-                if (p.accept_bits != nullptr) __builtin_nontemporal_store((uint8_t)((took >> lane) & 1u), p.accept_bits + slot);
+                if (wave_live) {
+                    if (p.samples != nullptr) __builtin_nontemporal_store(x, (float *)p.samples + slot);
+                    if (p.accept_bits != nullptr) __builtin_nontemporal_store((uint8_t)((took >> lane) & 1u), p.accept_bits + slot);
+                }
             }
         };
 
@@ -324,12 +368,48 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
         };
 
         // One group of 8 steps = 4 step pairs from 3 Philox blocks.  FAST: all 8 steps inside the launch (and before the
-        // tail when the launch hands a ring on): no range tests.  Otherwise every
-        // step is range-tested and, in the tail, stores its sample to the ring.
-        auto do_group = [&](auto fast_tag, uint64_t g) __attribute__((always_inline)) {
+        // tail when the launch hands a ring on): no range tests.  Otherwise every step is range-tested and, in the tail,
+        // stores its sample to the ring.
+        // PIPE (fast groups of the pipelined loop): every step is followed by two MFMAs of the block BEFORE the one being
+        // stepped through (complete in the other half of the ring): step `slot` of group parity ODD forms tile d = slot & 3
+        // of quarter q = 2 ODD + (slot >> 2).  A wave's MFMAs then sit between its own vector instructions instead of
+        // forming a burst of 32 during which it issues nothing else.
+        lag_half8 pa = {}, pasw = {}, ps0 = {};
+        auto do_group = [&](auto fast_tag, auto pipe_tag, auto odd_tag, uint64_t g) __attribute__((always_inline)) {
             constexpr bool FAST = decltype(fast_tag)::value;
+            constexpr bool PIPE = decltype(pipe_tag)::value;
+            constexpr int ODD = decltype(odd_tag)::value;
             Spare sp = {};
             uint32_t *ygrp = yw + (int)((g & 3) << 3) * LAG_PITCH + lane;
+            const int halfp = 16 - 16 * (int)((g >> 1) & 1); // the half of the block before the one being stepped
+            const uint32_t *prevA = yw + (halfp + r16) * LAG_PITCH + 4 * g4;
+            const uint32_t *prevS = yw + ((halfp + r16 + 31) & 31) * LAG_PITCH + 4 * g4;
+            auto pipe_slot = [&](auto slot_tag) __attribute__((always_inline)) {
+                constexpr int slot = decltype(slot_tag)::value;
+                constexpr int q = 2 * ODD + (slot >> 2), d = slot & 3;
+                if constexpr (d == 0) {
+                    pa = *reinterpret_cast<const lag_half8 *>(prevA + 16 * q);
+                    ps0 = *reinterpret_cast<const lag_half8 *>(prevS + 16 * q);
+                    uint4 u = __builtin_bit_cast(uint4, pa);
+                    u.x = __builtin_amdgcn_alignbit(u.x, u.x, 16);
+                    u.y = __builtin_amdgcn_alignbit(u.y, u.y, 16);
+                    u.z = __builtin_amdgcn_alignbit(u.z, u.z, 16);
+                    u.w = __builtin_amdgcn_alignbit(u.w, u.w, 16);
+                    pasw = __builtin_bit_cast(lag_half8, u);
+                    C[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, ps0, C[0], 0, 0, 0);
+                    C[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pasw, ps0, C[0], 0, 0, 0);
+                } else {
+                    C[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, S[d - 1][q], C[d], 0, 0, 0);
+                    C[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pasw, S[d - 1][q], C[d], 0, 0, 0);
+                }
+                if constexpr (d == 3) {
+                    S[2][q] = S[1][q];
+                    S[1][q] = S[0][q];
+                    S[0][q] = ps0;
+                }
+                // nothing but vector / scalar / memory instructions may move across: the MFMAs stay where they are
+                __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x80 | 0x100 | 0x200);
+            };
             auto body = [&](auto j_tag) __attribute__((always_inline)) {
                 constexpr int Jp = decltype(j_tag)::value;
                 float z0 = 0, z1 = 0, u0 = 0, u1 = 0;
@@ -340,7 +420,9 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
                 const uint64_t t0 = (g << 3) + 2 * Jp;
                 if constexpr (FAST) {
                     one_step(t0, ygrp + (2 * Jp) * LAG_PITCH, z0, u0);
+                    if constexpr (PIPE) pipe_slot(std::integral_constant<int, 2 * Jp>{});
                     one_step(t0 + 1, ygrp + (2 * Jp + 1) * LAG_PITCH, z1, u1);
+                    if constexpr (PIPE) pipe_slot(std::integral_constant<int, 2 * Jp + 1>{});
                 } else {
 #pragma unroll
                     for (int o = 0; o < 2; ++o) {
@@ -354,38 +436,62 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
             };
             expand_sequence(body, std::make_integer_sequence<int, 4>{});
         };
+        constexpr std::true_type YES{};
+        constexpr std::false_type NO{};
+        constexpr std::integral_constant<int, 0> EVEN{};
+        constexpr std::integral_constant<int, 1> ODDG{};
 
-        if (t_begin < t_end) {
-            const uint64_t g_first = t_begin >> 3, g_end = (t_end + 7) >> 3; // exclusive
-            const uint64_t g_fast = (t_begin + 7) >> 3, g_fast_end = (p.ring != nullptr ? tail_begin : t_end) >> 3;
-#pragma unroll 1
-            for (uint64_t g = g_first; g < g_end; ++g) {
-                const bool fast = g >= g_fast && g < g_fast_end;
-                if (fast) do_group(std::true_type{}, g);
-                else do_group(std::false_type{}, g);
-                // the block's last step is the last step of an odd group; the launch's last block may end before it
-                const bool last = g + 1 == g_end;
-                if ((g & 1) || last) {
-                    const uint64_t J = g >> 1;
-                    const int lo = J == J0 ? (int)(t_begin & 15) : 0;
-                    const int hi = ((J + 1) << 4) <= t_end ? LAG_BLK : (int)(t_end & 15);
-                    const bool want_rows = (J << 4) < head_end || ((J + 1) << 4) > tail_begin;
-#if !defined(MCMC_LAG_EXPERIMENT) || MCMC_LAG_EXPERIMENT < 1
-                    lag_block(J, lo, hi, want_rows);
+#ifdef MCMC_LAG_PHASES
+        if constexpr (STAMP) ph_pro += __builtin_amdgcn_s_memtime() - ph_mark;
 #endif
+        if (t_begin < t_end) {
+            const uint64_t J_last = (t_end - 1) >> 4;
+            const uint64_t fast_end_t = p.ring != nullptr ? tail_begin : t_end;
+            bool pending = false; // block J - 1 is complete in the ring and its products have not been formed yet
+#pragma unroll 1
+            for (uint64_t J = J0; J <= J_last; ++J) {
+                const bool fast = (J << 4) >= t_begin && ((J + 1) << 4) <= fast_end_t;
+                // A block that holds head or tail steps (four at either end of a window) is not pipelined: its row sums.
+                // (Pipelining them too -- a third instantiation of the groups, or the row sums read back from the ring --
+                // measured slower: the register allocation of the whole loop nest changes, 203 against 194 cycles.)
+                const bool rows_prev = pending && wants_rows(J - 1);
+                if (fast && pending && !rows_prev) {
+                    do_group(YES, YES, EVEN, 2 * J);
+                    do_group(YES, YES, ODDG, 2 * J + 1);
+                    if (++blocks_since_flush >= LAG_FLUSH) flush_tiles(16 - 16 * (int)(J & 1)); // block J - 1's half (but row 15)
+                } else {
+                    if (pending) lag_block(J - 1, 0, LAG_BLK);
+                    pending = false;
+                    if (fast) {
+                        do_group(YES, NO, EVEN, 2 * J);
+                        do_group(YES, NO, ODDG, 2 * J + 1);
+                        pending = true;
+                    } else {
+                        if ((J << 4) + 8 > t_begin) do_group(NO, NO, EVEN, 2 * J);
+                        if ((J << 4) + 8 < t_end) do_group(NO, NO, ODDG, 2 * J + 1);
+                        lag_block(J, J == J0 ? (int)(t_begin & 15) : 0, ((J + 1) << 4) <= t_end ? LAG_BLK : (int)(t_end & 15));
+                    }
                 }
-                if ((g & 15) == 15) flush(); // the float partial sums are folded into FP64 every <= 128 steps
+                if ((J & 7) == 7) flush(); // the float partial sums are folded into FP64 every <= 128 steps
             }
+            if (pending) lag_block(J_last, 0, LAG_BLK);
+#ifdef MCMC_LAG_PHASES
+            if constexpr (STAMP) ph_mark = __builtin_amdgcn_s_memtime();
+#endif
             flush();
-            flush_tiles((t_end - 1) >> 4);
+            flush_tiles(0);
         }
 
         if (valid) *state = x;
+        (void)wave_live;
 
         S1acc += valid ? S1 : 0.0; // in units of s and s^2
         S2acc += valid ? S2 : 0.0;
         wacc_all += wacc;
         lag_wave_fence();
+#ifdef MCMC_LAG_PHASES
+        if constexpr (STAMP) ph_epi += __builtin_amdgcn_s_memtime() - ph_mark;
+#endif
     }
 
     {
@@ -401,7 +507,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
     if (tid < len) {
         double tot = 0.0;
 #pragma unroll
-        for (int w = 0; w < CHAIN_WAVES; ++w) tot += sred[w][tid];
+        for (int w = 0; w < LAG_WAVES; ++w) tot += sred[w][tid];
         p.partials[((uint64_t)coord * gridDim.x + blockIdx.x) * len + tid] = tot;
     }
     if constexpr (STAMP) {
@@ -409,8 +515,14 @@ __global__ __launch_bounds__(CHAIN_BLOCK, MCMC_LAGM_BLOCKS_PER_CU) void chain_la
         const uint64_t dr = __builtin_amdgcn_s_memrealtime() - stamp_r;
         if (tid == 0 && p.stamps != nullptr) {
             uint64_t *o = p.stamps + ((uint64_t)coord * gridDim.x + blockIdx.x) * 2;
+#ifdef MCMC_LAG_PHASES
+            (void)dr;
+            o[0] = (ph_pro & 0xffffffffull) | (ph_epi << 32);
+            o[1] = dc;
+#else
             o[0] = dc;
             o[1] = dr;
+#endif
         }
     }
 }

@@ -14,18 +14,20 @@ using namespace mcmc;
 
 namespace {
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device instead of on every launch
-template <typename K>
-int ensure_dynamic_lds(K kernel, size_t lds)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per KERNEL and device instead of on every launch.  The cache is a
+// static inside a template over the kernel itself: every sab_kernel instantiation has the same function-pointer TYPE, so a
+// cache keyed on the type was one cache for all of them and skipped the attribute for every kernel after the first.
+template <auto Kernel>
+int ensure_dynamic_lds(size_t lds)
 {
     static std::atomic<size_t> granted[64];
     if (lds <= 48 * 1024) return MCMC_OK;
     int dev = 0;
     MCMC_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) dev = 0, granted[0].store(0);
-    if (granted[dev].load(std::memory_order_acquire) >= lds) return MCMC_OK;
-    MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    granted[dev].store(lds, std::memory_order_release);
+    const bool cached = dev >= 0 && dev < 64;
+    if (cached && granted[dev].load(std::memory_order_acquire) >= lds) return MCMC_OK;
+    MCMC_HIP_CHECK(hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (cached) granted[dev].store(lds, std::memory_order_release);
     return MCMC_OK;
 }
 
@@ -38,8 +40,8 @@ int launch_sab_g(const mcmc_xs_args *a, const XsParams &p, size_t lds, hipStream
     const bool inj = a->injected != nullptr;
 #define MCMC_SAB_LAUNCH(RULE, MATH, INJ)                                  \
     do {                                                                  \
-        auto k = sab_kernel<G, KIND, RULE, MATH, INJ, MODE>;              \
-        const int rc_lds = ensure_dynamic_lds(k, lds);                    \
+        constexpr auto k = sab_kernel<G, KIND, RULE, MATH, INJ, MODE>;    \
+        const int rc_lds = ensure_dynamic_lds<k>(lds);                    \
         if (rc_lds != MCMC_OK) return rc_lds;                             \
         hipLaunchKernelGGL(k, grid, block, lds, s, p);                    \
     } while (0)

@@ -59,6 +59,28 @@ def test_stepsize_driver_statistics_file(dev, tmp_path):
 
 
 @pytest.mark.gpu
+def test_stepsize_driver_gaussian_target_config0(dev, tmp_path):
+    """BASELINE configs[0] as stated: the 1-D Gaussian-target integration (R2Gaussian, metropolis.hpp:14-17, variance 1),
+    1024 chains x 1e4 steps in the reference's FP64 arithmetic.  Known answers for r^2 exp(-r^2/2): <r> = 1.595769,
+    <r^2> = 3, so the variance is 3 - 1.595769^2 = 0.453521; efficiency.txt carries both."""
+    r = subprocess.run([STEPSIZE, "--target", "r2gauss", "--chains", "1024", "--iterations", "10000", "--warmup", "500",
+                        "--first", "150", "--last", "250", "--stride", "100", "--outdir", str(tmp_path)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    stats = np.loadtxt(tmp_path / "statistics.txt", comments="#")
+    eff = np.loadtxt(tmp_path / "efficiency.txt", comments="#")
+    assert stats.shape == (2, 51) and eff.shape == (2, 6)
+    n = 1024 * 10000
+    for row in eff:
+        width, acc, tau, efficiency, mean, var = row
+        se = np.sqrt(0.453521 * tau / n)
+        assert abs(mean - 1.595769) < 4 * se + 1e-4, (width, mean, se)
+        assert abs(var - 0.453521) < 5e-3
+        assert 0.3 < acc < 0.7 and 1.0 < tau < 20.0 and efficiency == pytest.approx(1.0 / tau, rel=1e-5)
+    assert np.all(np.diff(stats[0, 2:12]) < 0)       # rho_k falls with k at the first lags
+
+
+@pytest.mark.gpu
 def test_stepsize_driver_single_chain_samples(dev, tmp_path):
     """One chain with --samples reproduces the reference's per-width sample files (fileio.hpp:8-17)."""
     r = subprocess.run([STEPSIZE, "--chains", "1", "--iterations", "2000", "--first", "248", "--last", "248",

@@ -687,6 +687,47 @@ def test_heavy_nucleus_r2_known_answer(dev, nucleus, A, c, a, r2):
     assert se < 0.02
 
 
+@pytest.mark.parametrize("nucleus,A,c,a,r2", [("Au-197", 197, 6.38, 0.535, 28.377538), ("Pb-208", 208, 6.62, 0.546, 30.413841)])
+def test_heavy_nucleus_full_size_properties(dev, nucleus, A, c, a, r2):
+    """BASELINE configs[2] AT ITS STATED SIZE: 2^22 coordinate chains (2^22 / A events x A nucleons) of the Au-197 / Pb-208
+    Woods-Saxon density, through size-independent properties: slices of the event id space re-run as small engines with
+    event_offset (the first events, an unaligned middle, the last ones) reproduce the big run's chain states and
+    per-thread r^2 means bit for bit (what makes the 1/2/4/8-GPU partition exact); the device run means equal the FP32
+    Kahan average of the result rows; <r^2> over all nucleons agrees with quadrature within 3 standard
+    errors of the run-to-run scatter (width 3.9 fm: the device study's optimum for these densities)."""
+    T = (1 << 22) // A
+    tg = [(O.R2WS, c, a)] * A
+    kw = dict(seed=20250611)
+    big = _xs(dev, A, 0, T, tg, "cross_fast", **kw)
+    big.InitSampleFromPdf()
+    big.WarmupMetropolis(64, stepsize=3.9)
+    start = big.prevSample.clone()
+    res, run_mean = big.MCIntegrate_R2(128, stepsize=3.9)
+    torch.cuda.synchronize()
+    res_big, state_big, mean_big = res.clone(), big.prevSample.clone(), run_mean.cpu().numpy().copy()
+    for off, cnt in ((0, 300), (T // 2 + 13, 517), (T - 77, 77)):
+        part = _xs(dev, A, 0, cnt, tg, "cross_fast", event_offset=off, **kw)
+        part.prevSample.copy_(start[:, off:off + cnt])
+        part.args.step_offset = 64
+        r, _ = part.MCIntegrate_R2(128, stepsize=3.9)
+        torch.cuda.synchronize()
+        assert torch.equal(part.prevSample, state_big[:, off:off + cnt]), off
+        assert torch.equal(r, res_big[:, off:off + cnt]), off
+    rows = res_big.cpu().numpy()
+    for n in (0, A // 2, A - 1):
+        assert mean_big[n] == pytest.approx(rows[n].astype(np.float64).mean(), rel=1e-12)
+    means = [mean_big.mean()]
+    for _ in range(7):
+        _, rm = big.MCIntegrate_R2(128, stepsize=3.9)
+        torch.cuda.synchronize()
+        means.append(rm.cpu().numpy().mean())
+    means = np.array(means)
+    est, se = means.mean(), means.std(ddof=1) / np.sqrt(len(means))
+    print(f"{nucleus}: <r^2> = {est:.5f} +/- {se:.5f} (quadrature {r2})")
+    assert abs(est - r2) < 3 * se + 2e-4 * r2, (nucleus, est, se, r2)
+    assert se < 5e-3
+
+
 @pytest.mark.parametrize("kernel", ["warmup_r2", "sab", "inel"])
 def test_log_space_rule_on_the_xsection_kernels(dev, kernel):
     """north_star subsystem (1), log-space acceptance, on the kernels that replace Metropolis.cuh:47-50: the LOG rule
