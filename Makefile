@@ -94,7 +94,7 @@ tools/bin/dist_probe: tools/dist_probe.hip include/mcmc_distributions.h
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Iinclude -o $@ $<
 
 # VALU issue-rate microbenchmark (calibrates the cycle model of tools/isa_mix.py)
-ubench: tools/bin/ubench tools/bin/ubench2 tools/bin/ubench3 tools/bin/ubench_cal tools/bin/ubench_mfma
+ubench: tools/bin/ubench tools/bin/ubench2 tools/bin/ubench3 tools/bin/ubench_cal tools/bin/ubench_mfma tools/bin/ubench_store tools/bin/ubench_store_valu
 tools/bin/%: tools/%.hip
 	@mkdir -p tools/bin
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -o $@ $<

@@ -171,6 +171,14 @@ def secondary(dev):
         t = timed(lambda: eng.run(S, samples=smp))
         out["chain_writeback_proposals_per_s"] = nc * C * S / t
         out["chain_writeback_algorithmic_GBps"] = (nc * C * S * 4 + 2 * 4 * nc * C) / t / 1e9
+        # the same launch in the pair layout [S / 2][C][nc][2]: one 64-bit store per lane and step pair (A/B of the store path)
+        L.check(L.lib.mcmc_set_option(b"MCMC_SAMPLES_PAIRS", b"1"))
+        try:
+            t = timed(lambda: eng.run(S, samples=smp))
+        finally:
+            L.lib.mcmc_set_option(b"MCMC_SAMPLES_PAIRS", None)
+        out["chain_writeback_pairs_proposals_per_s"] = nc * C * S / t
+        out["chain_writeback_pairs_algorithmic_GBps"] = (nc * C * S * 4 + 2 * 4 * nc * C) / t / 1e9
         del eng, smp
         # the headline workload under the log-space rule (north_star (1)) and under the reference's cached-reciprocal rule
         for name, rule in (("log", L.ACCEPT_LOG), ("recip", L.ACCEPT_RECIP)):
@@ -499,14 +507,16 @@ def main(argv=None):
         if args.workload == "chain":
             # HBM bytes per launch: NOT measured in this run -- the committed PMC passes of this same workload
             # (tools/gpu_profile.sh; FETCH_SIZE / WRITE_SIZE in their own runs, FETCH doubled per MI355X_MICROARCH.md)
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_chain_kernel.json")))
-                if args.chains == 1 << 24 and args.coords == 3 and args.lags == 0:
-                    roof["traffic"] = pm["derived"]["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = ("profiles/r2_pmc_chain_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                              "this workload, tools/gpu_profile.sh; not measured in this run)")
-            except (OSError, KeyError, ValueError):
-                pass
+            for prof in ("r3_pmc_chain_kernel.json", "r2_pmc_chain_kernel.json"):   # this round's passes, else the round before's
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                    if args.chains == 1 << 24 and args.coords == 3 and args.lags == 0:
+                        roof["traffic"] = pm["derived"]["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = (f"profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                  "this workload, tools/gpu_profile.sh; not measured in this run)")
+                    break
+                except (OSError, KeyError, ValueError):
+                    pass
             roof["note"] = ("FP32 VALU-issue-bound (state in registers, no per-step HBM traffic). achieved = 24 algorithmic "
                             "FP32 flop per proposal (SURVEY 8d) / kernel time; Philox integer work and quarter-rate "
                             "transcendentals are not counted as flops, so frac understates VALU occupancy: valu_issue sets "
@@ -597,13 +607,15 @@ def main(argv=None):
         e2.run(256, window_start=True, n_lags=L.MAX_LAGS)
         torch.cuda.synchronize()
         rates = {}
-        for lag_sweeps in (1024, 4096):   # a step-size study's launches are 10^3 - 10^4 sweeps (C2: 10^4)
-            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lag_launches = {1024: 4, 4096: 2}
+        for lag_sweeps, reps in lag_launches.items():   # a step-size study's launches are 10^3 - 10^4 sweeps (C2: 10^4),
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # one after the other
             ea.record()
-            e2.run(lag_sweeps, window_start=True, n_lags=L.MAX_LAGS)
+            for _ in range(reps):
+                e2.run(lag_sweeps, window_start=True, n_lags=L.MAX_LAGS)
             eb.record()
             torch.cuda.synchronize()
-            rates[lag_sweeps] = sub * args.coords * lag_sweeps / (ea.elapsed_time(eb) * 1e-3)
+            rates[lag_sweeps] = reps * sub * args.coords * lag_sweeps / (ea.elapsed_time(eb) * 1e-3)
         tau = e2.summary()[0]["tau_int"]
         if out is not None:
             out["tau_int"] = tau
@@ -612,6 +624,7 @@ def main(argv=None):
             out["ess_per_sec"] = value / tau
             out["lag49_proposals_per_sec_per_gpu"] = rates[4096]
             out["lag49_sweeps_per_launch"] = 4096
+            out["lag49_launches_timed"] = lag_launches   # back to back between two events; one statistics window per launch
             out["lag49_proposals_per_sec_per_gpu_1024_sweeps"] = rates[1024]
             out["ess_per_sec_lag49_kernel"] = n_gpus * rates[4096] / tau
             out["lag49_kernel"] = "mcmc::chain_lag_kernel (v_mfma_f32_16x16x32_f16)" if os.environ.get("MCMC_LAG_MFMA", "1") != "0" \

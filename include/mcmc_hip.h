@@ -460,7 +460,13 @@ int mcmc_isotope(const char *name, int *Z, int *A);
  * "MCMC_SAB_CULL" ("0" = exact pair culling off), "MCMC_SAB_SMALL" ("0" / "1" = general / register kernel for nuclei of
  * at most 4 + 4 nucleons), "MCMC_SAB_PLAN" ("G,ga_log2").  The environment variables of the same names are read once,
  * at the first S_AB launch; this call overrides them for the process (value NULL = default).  Results do not depend
- * on them beyond the order of float multiplications.                                                            */
+ * on them beyond the order of float multiplications.
+ * Chain kernels: "MCMC_MVN_REG" ("0" / "1" = LDS / register kernel of the stress target), "MCMC_LAG_MFMA" ("0" = the
+ * 49 lag products of FP32 chains on the vector unit instead of the matrix cores: same chains, lag sums equal to
+ * FP32 rounding), "MCMC_SAMPLES_PAIRS" ("1" = mcmc_chain_args.samples is written as [n_steps / 2][n_coords][n_chains][2],
+ * two consecutive steps of a chain side by side -- one 64-bit store per lane and step pair; FP32 FAST-math Philox
+ * launches without lags or accept flags, step_offset and n_steps even, else MCMC_EINVAL; the values are those of the
+ * default layout bit for bit).                                                                                   */
 int mcmc_set_option(const char *name, const char *value);
 
 const char *mcmc_last_error(void);

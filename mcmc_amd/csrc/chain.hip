@@ -24,6 +24,7 @@ int chain_dispatch_kind_3(const mcmc_chain_args *, const ChainParams &, dim3, hi
 
 namespace mcmc {
 int g_lag_mfma = -1; // MCMC_LAG_MFMA: 0 = lag products on the VALU (chain_kernel), otherwise chain_lag_kernel; -1 = not read yet
+int g_samples_pairs = -1; // MCMC_SAMPLES_PAIRS: 1 = sample write-back in the pair layout; -1 = not read yet
 }
 
 namespace {
@@ -35,6 +36,15 @@ bool lag_mfma_enabled()
         g_lag_mfma = v && v[0] == '0' ? 0 : 1;
     }
     return g_lag_mfma != 0;
+}
+
+bool samples_pairs_enabled()
+{
+    if (g_samples_pairs < 0) {
+        const char *v = std::getenv("MCMC_SAMPLES_PAIRS");
+        g_samples_pairs = v && v[0] == '1' ? 1 : 0;
+    }
+    return g_samples_pairs != 0;
 }
 
 // chain_lag_kernel stores y s as two f16 halves: s = the power of two that maps the farthest |x - center| a chain of this
@@ -114,10 +124,18 @@ int chain_launch(const mcmc_chain_args *a, void *workspace, size_t workspace_byt
     p.stamps = stamps;
     p.lag_mfma = a->precision == 32 && a->n_lags > 0 && lag_mfma_enabled();
     p.lag_scale = lag_scale_for(a);
+    p.samples_pairs = 0;
+    if (a->samples != nullptr && samples_pairs_enabled()) {
+        // the pair layout exists for the throughput form of the write-back path only (mcmc_hip.h)
+        if (a->precision != 32 || a->math_mode != MCMC_MATH_FAST || a->n_lags != 0 || a->inj_normals || a->accept_bits ||
+            a->n_chains >= (1ull << 29) || (a->step_offset & 1) || (a->n_steps & 1))
+            return set_error(MCMC_EINVAL, "MCMC_SAMPLES_PAIRS: FP32 FAST-math Philox launches without lags or accept flags, "
+                                          "step_offset and n_steps even, n_chains < 2^29");
+        p.samples_pairs = 1;
+    }
 
     hipStream_t s = (hipStream_t)stream;
-    // FP32 with lags: 768-thread workgroups of chain_lag_kernel (never more of them than the 256-thread tiles the
-    // workspace is sized for)
+    // FP32 with lags: chain_lag_kernel, one 256-chain tile per workgroup like chain_kernel (the workspace is sized for either)
     const dim3 grid(p.lag_mfma ? lag_grid_x(a->n_chains) : chain_grid_x(a->n_chains), a->n_coords);
     int rc;
     switch (a->target.kind) {

@@ -41,6 +41,7 @@ struct ChainParams {
     uint8_t *accept_bits;
     float lag_scale;  // chain_lag_kernel: power of two that maps |x - center| into f16's normal range
     int lag_mfma;     // FP32 with lags: 1 = chain_lag_kernel (lag products on the matrix cores), 0 = the VALU form below
+    int samples_pairs; // samples in the pair layout [n_steps / 2][n_coords][n_chains][2] (STORE == 3)
     uint64_t *stamps; // STAMP instantiation only: [n_coords][gridDim.x][2] = shader cycles, 100 MHz ticks of the block's tile loop
 };
 
@@ -60,7 +61,9 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 // STORE: 0 = no write-back; 1 = sample and / or accept-flag write-back (which of the two is tested at run time);
 //        2 = samples only, FP32 FAST-math Philox kernels without lags (the throughput case of the write-back path):
 //            no run-time tests in the step, the row (step, coordinate) addressed by a wave-uniform base + the lane's
-//            32-bit byte offset
+//            32-bit byte offset;
+//        3 = as 2 in the pair layout samples[n_steps / 2][n_coords][n_chains][2] (option "MCMC_SAMPLES_PAIRS"): two
+//            consecutive steps of a chain leave as one 64-bit store (step_offset and n_steps even)
 // STAMP: diagnostic instantiation (mcmc_chain_clock_probe) -- the same body with one s_memtime / s_memrealtime pair
 //        around the block's tile loop, written to a buffer of their own; no production launch executes a stamp
 template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ, int STORE, bool STAMP = false>
@@ -120,6 +123,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
         const uint32_t lane_off_b = (uint32_t)ch * (uint32_t)sizeof(Real); // STORE == 2: n_chains < 2^30 (launch_chain)
         const uint32_t row_bytes = (uint32_t)nc * (uint32_t)sizeof(Real);  // one row samples[t][coord][0 .. nc)
         (void)lane_off_b, (void)row_bytes;
+        float x_even = 0.0f; // STORE == 3: the sample of the pair's first step
+        (void)x_even;
 
         // this chain's draw stream: the block-independent part of Philox rounds 1-2 (device_common.hpp).  Not with the
         // lag products: that kernel sits at its register cap and the five words more cost it 10 % (measured).
@@ -237,6 +242,14 @@ __global__ __launch_bounds__(CHAIN_BLOCK, (NLAG > 0 && sizeof(Real) == 4) ? MCMC
             if constexpr (STORE == 2) {
                 const Real *rowp = (const Real *)p.samples + ((t - t_begin) * p.n_coords + coord) * nc; // uniform
                 store_row_f32(reinterpret_cast<const float *>(rowp), row_bytes, lane_off_b, (float)x);
+            }
+            if constexpr (STORE == 3) {
+                if ((t & 1) == 0) { // t_begin is even: the parity of t is the parity within the launch
+                    x_even = (float)x;
+                } else {
+                    const Real *rowp = (const Real *)p.samples + (((t - t_begin) >> 1) * p.n_coords + coord) * nc * 2; // uniform
+                    store_row_f32x2(reinterpret_cast<const float *>(rowp), 2 * row_bytes, 2 * lane_off_b, x_even, (float)x);
+                }
             }
             if constexpr (STORE == 1) {
                 // written once, never re-read by this kernel: streaming (nt) stores keep them out of L2's way
@@ -448,6 +461,10 @@ template <typename Real, int KIND, int RULE, int MATH, int NLAG, bool INJ>
 void launch_chain(const ChainParams &p, dim3 grid, hipStream_t s)
 {
     if constexpr (sizeof(Real) == 4 && MATH == MCMC_MATH_FAST && NLAG == 0 && !INJ) {
+        if (p.samples != nullptr && p.samples_pairs) { // chain_launch has checked the layout's conditions
+            hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, 3>), grid, dim3(CHAIN_BLOCK), 0, s, p);
+            return;
+        }
         if (p.samples != nullptr && p.accept_bits == nullptr && p.n_chains < (1ull << 30)) {
             hipLaunchKernelGGL((chain_kernel<Real, KIND, RULE, MATH, NLAG, INJ, 2>), grid, dim3(CHAIN_BLOCK), 0, s, p);
             return;

@@ -563,6 +563,17 @@ __device__ __forceinline__ void store_row_f32(const float *row, uint32_t row_byt
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)lane_off_b, 0, 2 /* nt */);
 }
 
+// Two samples per lane (consecutive steps of one chain) as ONE 64-bit store into a row of pairs
+// out[0 .. row_bytes/8)[2]: half the vector-memory instructions of store_row_f32 for the same bytes (the
+// "MCMC_SAMPLES_PAIRS" layout of mcmc_hip.h).  lane_off_b = 8 * chain.
+__device__ __forceinline__ void store_row_f32x2(const float *row, uint32_t row_bytes, uint32_t lane_off_b, float v0, float v1)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, (int)row_bytes, 0x00020000);
+    const u32x2 v = {__builtin_bit_cast(unsigned int, v0), __builtin_bit_cast(unsigned int, v1)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)lane_off_b, 0, 2 /* nt */);
+}
+
 // ---------------------------------------------------------------------
 // Wavefront (64 lanes) reductions with DPP row operations, then the two
 // cross-row steps through the permute network; block reductions through LDS.

@@ -23,7 +23,8 @@ int launch_sab_mode_4(const mcmc_xs_args *, const XsParams &, int G, size_t lds,
 
 namespace mcmc {
 extern int g_mvn_reg;  // mvn.hip
-extern int g_lag_mfma; // chain.hip
+extern int g_lag_mfma;      // chain.hip
+extern int g_samples_pairs; // chain.hip
 }
 
 namespace {
@@ -294,8 +295,12 @@ extern "C" int mcmc_set_option(const char *name, const char *value)
         g_lag_mfma = value && value[0] == '0' ? 0 : 1;
         return MCMC_OK;
     }
+    if (std::strcmp(name, "MCMC_SAMPLES_PAIRS") == 0) { // chain sample write-back: 1 = [n_steps / 2][n_coords][n_chains][2]
+        g_samples_pairs = value && value[0] == '1' ? 1 : 0;
+        return MCMC_OK;
+    }
     if (std::strcmp(name, "MCMC_SAB_CULL") && std::strcmp(name, "MCMC_SAB_SMALL") && std::strcmp(name, "MCMC_SAB_PLAN"))
-        return set_error(MCMC_EINVAL, "unknown option (MCMC_SAB_CULL, MCMC_SAB_SMALL, MCMC_SAB_PLAN, MCMC_MVN_REG, MCMC_LAG_MFMA)");
+        return set_error(MCMC_EINVAL, "unknown option (MCMC_SAB_CULL, MCMC_SAB_SMALL, MCMC_SAB_PLAN, MCMC_MVN_REG, MCMC_LAG_MFMA, MCMC_SAMPLES_PAIRS)");
     (void)sab_options(); // the environment first, so that this call wins
     std::lock_guard<std::mutex> lock(opt_mutex);
     parse_option(opt_state, name, value);

@@ -157,6 +157,37 @@ def test_samples_only_writeback_kernel_equals_the_general_one(dev):
     assert torch.equal(sa[-1], a.state)
 
 
+def test_pair_layout_writeback_holds_the_same_samples(dev):
+    """Option MCMC_SAMPLES_PAIRS (mcmc_hip.h): samples[n / 2][coords][chains][2], two consecutive steps of a chain as one
+    64-bit store -- the default layout's values bit for bit (ragged chain count, many tiles, launch at an even offset inside
+    a draw group); odd step counts / offsets and launches the layout does not cover are refused."""
+    from mcmc_amd import lib as L
+    N, n = 2048 * 256 + 300 + 77, 22
+    kw = dict(n_chains=N, n_coords=2, target=R2WS_REF, step=2.48, precision=32, accept_rule=L.ACCEPT_CROSS,
+              math_mode=L.MATH_FAST, seed=5, center=2.3)
+    a, b = _engine(dev, **kw), _engine(dev, **kw)
+    a.run(6), b.run(6)
+    sa = torch.full((n, 2, N), -1.0, dtype=torch.float32, device=dev)
+    sb = torch.full((n // 2, 2, N, 2), -2.0, dtype=torch.float32, device=dev)
+    ta = a.run(n, samples=sa).clone()
+    L.check(L.lib.mcmc_set_option(b"MCMC_SAMPLES_PAIRS", b"1"))
+    try:
+        tb = b.run(n, samples=sb).clone()
+        torch.cuda.synchronize()
+        with pytest.raises(L.McmcError):
+            b.run(3, samples=sb)                      # odd step count
+        with pytest.raises(L.McmcError):
+            b.run(4, samples=sb, accept_bits=torch.zeros((4, 2, N), dtype=torch.uint8, device=dev))
+    finally:
+        L.lib.mcmc_set_option(b"MCMC_SAMPLES_PAIRS", None)
+    # [n/2][c][N][2] -> [n/2][2][c][N] -> [n][c][N]
+    assert torch.equal(sb.permute(0, 3, 1, 2).reshape(n, 2, N), sa)
+    assert torch.equal(a.state, b.state) and torch.equal(ta, tb)
+    c = _engine(dev, **kw)
+    c.run(7)                                          # an odd offset under the default layout is fine
+    c.run(2, samples=sa[:2])
+
+
 def test_philox_mode_trajectory_matches_oracle_on_device_draws(dev, oracle):
     """Philox mode == injected mode fed with the library's own draws (logic parity at any seed)."""
     from mcmc_amd import lib as L
