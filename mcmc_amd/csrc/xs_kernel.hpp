@@ -370,6 +370,75 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
 {
     // nAe / nBe: the A nucleons trE[0 .. nAe) and B nucleons trE[p.nA .. p.nA + nBe) that take part (all of them,
     // or what sab_cull kept)
+    if constexpr (MATH == MCMC_MATH_FAST && JC % 2 == 0) {
+        // Two B nucleons per register pair: every operation of the pair term is a packed-FP32 instruction on two pairs
+        // (v_pk_add / mul / fma_f32: 4.2 issue cycles for two results against 2 x 3.1, tools/ubench_cal.hip) except
+        // v_exp_f32.  Same operations in the same order per pair as the scalar form below: bit-identical results.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        constexpr int H = JC / 2;
+        f2 bx[H], by[H], pr[H], cq[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint32_t j = lb + (q0 + 2 * h + s) * GB;
+                const bool ok = j < nBe;
+                const float2 v = trE[p.nA + (ok ? j : 0)];
+                bx[h][s] = ok ? v.x : 1.0e30f;
+                by[h][s] = ok ? v.y : 0.0f;
+            }
+            pr[h] = f2{1.0f, 1.0f};
+            cq[h] = f2{0.0f, 0.0f};
+        }
+        const HitScale hs = hit_scale(p.hit_d2);
+        const f2 neg_big2 = {hs.neg_big, hs.neg_big}, hit_big2 = {hs.hit_big, hs.hit_big};
+        const f2 one2 = {1.0f, 1.0f}, ng0 = {-p.G0, -p.G0};
+        uint32_t i = la;
+        if (i < nAe) {
+            float2 a = trE[i];
+            for (;;) {
+                const uint32_t in = i + GA;
+                const bool more = in < nAe;
+                const float2 an = trE[more ? in : i];
+                const f2 ax = {a.x, a.x}, ay = {a.y, a.y};
+                float dmin = __builtin_inff();
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const f2 dx = ax - bx[h];
+                    const f2 dy = ay - by[h];
+                    const f2 d2 = __builtin_elementwise_fma(dy, dy, dx * dx);
+                    if constexpr (PROD) {
+                        const f2 ex = {__builtin_amdgcn_exp2f(-d2[0]), __builtin_amdgcn_exp2f(-d2[1])};
+                        pr[h] *= __builtin_elementwise_fma(ng0, ex, one2);
+                    }
+                    if constexpr (HITS) {
+                        f2 t;
+                        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(d2), "v"(neg_big2), "v"(hit_big2));
+                        cq[h] += t;
+                        dmin = __builtin_fminf(__builtin_fminf(dmin, d2[0]), d2[1]); // one v_min3_f32
+                    }
+                }
+                if constexpr (HITS) {
+                    if (dmin < p.hit_d2) partE[i] = 1; // benign race: every writer stores 1
+                }
+                if (!more) break;
+                a = an;
+                i = in;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if constexpr (PROD) prod *= pr[h][s];
+                if constexpr (HITS) {
+                    ncoll += (uint32_t)cq[h][s];
+                    if (cq[h][s] != 0.0f) partE[p.nA + lb + (q0 + 2 * h + s) * GB] = 1; // a padded j never collides
+                }
+            }
+        }
+        return;
+    }
     float bx[JC], by[JC], pr[JC];
     float cq[JC]; // HITS: collisions of B nucleon q (per-q counters double as the participant flags); exact integers < 2^24
 #pragma unroll
