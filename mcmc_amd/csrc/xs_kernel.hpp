@@ -363,17 +363,22 @@ __device__ __forceinline__ float hit_indicator(float d2, const HitScale &h)
 // iteration ahead) and keeps JC of its B nucleons j = lb + GB*(q0+q) in registers.  In FAST math
 // the stored positions are pre-multiplied by sqrt(log2(e)/(2 beta)), so a pair costs
 // 2 sub + mul + fma + v_exp_f32 + fma + mul.
-template <int JC, int MATH, bool PROD, bool HITS>
+// CHECK (one event per wavefront, PROD): every eighth A iteration the wave tests whether the product over the pairs done
+// so far has underflowed to exactly 0 -- the remaining factors are finite and cannot change it.  With hit counters the
+// loop goes on without the product (no exp); without them the sample's scan ends.  `dead` in: skip the product from the
+// start; out: the product is 0.
+template <int JC, int MATH, bool PROD, bool HITS, bool CHECK = false>
 __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, uint8_t *partE, uint32_t nAe, uint32_t nBe,
                                           uint32_t la, uint32_t lb, uint32_t GA, uint32_t GB, uint32_t q0, float &prod,
-                                          uint32_t &ncoll)
+                                          uint32_t &ncoll, bool &dead)
 {
     // nAe / nBe: the A nucleons trE[0 .. nAe) and B nucleons trE[p.nA .. p.nA + nBe) that take part (all of them,
     // or what sab_cull kept)
     if constexpr (MATH == MCMC_MATH_FAST && JC % 2 == 0) {
         // Two B nucleons per register pair: every operation of the pair term is a packed-FP32 instruction on two pairs
-        // (v_pk_add / mul / fma_f32: 4.2 issue cycles for two results against 2 x 3.1, tools/ubench_cal.hip) except
-        // v_exp_f32.  Same operations in the same order per pair as the scalar form below: bit-identical results.
+        // (v_pk_add / mul / fma_f32) except v_exp_f32.  Same operations in the same order per pair as the scalar form
+        // below: bit-identical results.  The A loop has a wave-uniform trip count (absent nucleons sit at -1e30: d^2 = inf,
+        // factor exactly 1, never a hit), so that the whole wave can look at the product together.
         typedef float f2 __attribute__((ext_vector_type(2)));
         constexpr int H = JC / 2;
         f2 bx[H], by[H], pr[H], cq[H];
@@ -393,21 +398,27 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
         const HitScale hs = hit_scale(p.hit_d2);
         const f2 neg_big2 = {hs.neg_big, hs.neg_big}, hit_big2 = {hs.hit_big, hs.hit_big};
         const f2 one2 = {1.0f, 1.0f}, ng0 = {-p.G0, -p.G0};
-        uint32_t i = la;
-        if (i < nAe) {
-            float2 a = trE[i];
-            for (;;) {
-                const uint32_t in = i + GA;
-                const bool more = in < nAe;
-                const float2 an = trE[more ? in : i];
-                const f2 ax = {a.x, a.x}, ay = {a.y, a.y};
-                float dmin = __builtin_inff();
+        const float2 far = make_float2(-1.0e30f, 0.0f);
+        const uint32_t KA = (nAe + GA - 1) >> p.ga_log2;
+        bool alive = PROD && !(CHECK && dead); // wave-uniform
+        float2 a = la < nAe ? trE[la] : far;
+        for (uint32_t k = 0; k < KA; ++k) {
+            const uint32_t i = la + (k << p.ga_log2);
+            const uint32_t in = i + GA;
+            const bool more = in < nAe;
+            float2 an = trE[more ? in : 0];
+            if (!more) an = far;
+            const f2 ax = {a.x, a.x}, ay = {a.y, a.y};
+            float dmin = __builtin_inff();
+            // the B slices against this A nucleon, with (the product is alive) or without the Gamma factor
+            auto slices = [&](auto with_tag) __attribute__((always_inline)) {
+                constexpr bool WITH = decltype(with_tag)::value;
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
                     const f2 dx = ax - bx[h];
                     const f2 dy = ay - by[h];
                     const f2 d2 = __builtin_elementwise_fma(dy, dy, dx * dx);
-                    if constexpr (PROD) {
+                    if constexpr (WITH) {
                         const f2 ex = {__builtin_amdgcn_exp2f(-d2[0]), __builtin_amdgcn_exp2f(-d2[1])};
                         pr[h] *= __builtin_elementwise_fma(ng0, ex, one2);
                     }
@@ -418,13 +429,32 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
                         dmin = __builtin_fminf(__builtin_fminf(dmin, d2[0]), d2[1]); // one v_min3_f32
                     }
                 }
-                if constexpr (HITS) {
-                    if (dmin < p.hit_d2) partE[i] = 1; // benign race: every writer stores 1
+            };
+            if constexpr (PROD) {
+                if (alive) {
+                    slices(std::true_type{});
+                    if constexpr (CHECK) {
+                        if ((k & 7u) == 7u && k + 1 < KA) {
+                            float w = prod;
+#pragma unroll
+                            for (int h = 0; h < H; ++h) w *= pr[h][0] * pr[h][1];
+                            if (group_prod<64>(w) == 0.0f) {
+                                dead = true;
+                                alive = false;
+                                if constexpr (!HITS) break; // nothing but the product was wanted
+                            }
+                        }
+                    }
+                } else {
+                    slices(std::false_type{});
                 }
-                if (!more) break;
-                a = an;
-                i = in;
+            } else {
+                slices(std::false_type{});
             }
+            if constexpr (HITS) {
+                if (dmin < p.hit_d2) partE[i] = 1; // benign race: every writer stores 1 (an absent nucleon never hits)
+            }
+            a = an;
         }
 #pragma unroll
         for (int h = 0; h < H; ++h) {
@@ -439,6 +469,7 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
         }
         return;
     }
+    const bool with_prod = PROD && !(CHECK && dead); // wave-uniform
     float bx[JC], by[JC], pr[JC];
     float cq[JC]; // HITS: collisions of B nucleon q (per-q counters double as the participant flags); exact integers < 2^24
 #pragma unroll
@@ -467,10 +498,14 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
                 float d2;
                 if constexpr (MATH == MCMC_MATH_FAST) {
                     d2 = __builtin_fmaf(dy, dy, dx * dx);
-                    if constexpr (PROD) pr[q] *= __builtin_fmaf(-p.G0, __builtin_amdgcn_exp2f(-d2), 1.0f);
+                    if constexpr (PROD) {
+                        if (with_prod) pr[q] *= __builtin_fmaf(-p.G0, __builtin_amdgcn_exp2f(-d2), 1.0f);
+                    }
                 } else {
                     d2 = dx * dx + dy * dy;
-                    if constexpr (PROD) pr[q] *= 1 - p.G0 * expf(-d2 / p.twoBeta); // IntegrateSAB.cuh:12,75
+                    if constexpr (PROD) {
+                        if (with_prod) pr[q] *= 1 - p.G0 * expf(-d2 / p.twoBeta); // IntegrateSAB.cuh:12,75
+                    }
                 }
                 if constexpr (HITS) {
                     cq[q] += hit_indicator(d2, hs);
@@ -539,8 +574,9 @@ __device__ __forceinline__ bool sab_pairs_inel(const XsParams &p, const float2 *
 }
 
 // MODE bit 0: the S_AB product; bit 1: black-disk hit counters; MODE 4: inelastic flag only.
+// (product + counters: three blocks per CU are what its LDS allows, so the register allocation is held to 168 VGPRs)
 template <int G, int KIND, int RULE, int MATH, bool INJ, int MODE>
-__global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
+__global__ __launch_bounds__(XS_BLOCK, MODE == 3 ? 3 : 1) void sab_kernel(const XsParams p)
 {
     constexpr bool PROD = (MODE & 1) != 0;
     constexpr bool HITS = (MODE & 2) != 0;
@@ -771,11 +807,13 @@ __global__ __launch_bounds__(XS_BLOCK) void sab_kernel(const XsParams p)
         auto pass = [&](auto jc_tag) __attribute__((always_inline)) {
             constexpr int JC = decltype(jc_tag)::value;
             if constexpr (DROP0) {
-                if (dead) sab_pairs<JC, MATH, false, true>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll);
-                else sab_pairs<JC, MATH, true, true>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll);
+                // (the in-pass test of the product-only mode does not pay here: the product of a central event is gone after
+                // the first one-slice pass, and the two loop bodies cost 19 VGPRs -- measured 117 against 126 M event samples/s)
+                if (dead) sab_pairs<JC, MATH, false, true>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll, dead);
+                else sab_pairs<JC, MATH, true, true>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll, dead);
             } else {
                 if (dead) return;
-                sab_pairs<JC, MATH, PROD, HITS>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll);
+                sab_pairs<JC, MATH, PROD, HITS, EXIT0>(p, trE, partE, nAe, nBe, la, lb, GA, GB, q0, prod, ncoll, dead);
             }
             q0 += JC;
             if constexpr (EXIT0 || DROP0) {
