@@ -60,11 +60,10 @@ __host__ __device__ inline uint32_t lag_grid_x(uint64_t n_chains)
     return (uint32_t)(tiles < 2048 ? tiles : 2048);
 }
 
-// y s -> (h, l) as two f16 in one dword (h low).  |y s| is clamped below f16's largest value: a chain started far from
-// the target cannot poison the tiles with inf * 0.
-__device__ __forceinline__ uint32_t lag_pack_scaled(float ys_raw)
+// y s -> (h, l) as two f16 in one dword (h low).  The kernel runs with MODE.FP16_OVFL set: |y s| beyond f16's range
+// saturates at 65504 instead of becoming inf, so a chain started far from the target cannot poison the tiles with inf * 0.
+__device__ __forceinline__ uint32_t lag_pack_scaled(float ys)
 {
-    const float ys = __builtin_amdgcn_fmed3f(ys_raw, -65000.0f, 65000.0f);
     const float h = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, ys) & 0xFFFFE000u);
     const float l = ys - h;
     const lag_half2 pk = {(_Float16)h, (_Float16)l}; // v_cvt_pk_f16_f32 (round to nearest even)
@@ -87,6 +86,10 @@ __global__ __launch_bounds__(LAG_THREADS, 3) void chain_lag_kernel(const ChainPa
     __shared__ double sred[LAG_WAVES][LAG_STATS_MAX];
     __shared__ __attribute__((aligned(16))) uint32_t ybuf[LAG_WAVES][LAG_ROWS * LAG_PITCH];
 
+    // MODE.FP16_OVFL (hwreg(HW_REG_MODE, 23, 1)): a conversion to f16 that overflows gives +-65504, not +-inf -- the
+    // saturation lag_pack_scaled relies on, without a clamp per step (a v_med3_f32 there measured 2 % of the kernel).
+    // The mode belongs to the wave and ends with it.
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1u);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
