@@ -151,3 +151,48 @@ def test_far_start_saturates_instead_of_poisoning(dev):
     st = eng.run(100).cpu().numpy()
     torch.cuda.synchronize()
     assert np.all(np.isfinite(st))
+
+
+def test_randomised_windows_agree_with_the_valu_kernel(dev, lag_option):
+    """Random chain counts, lag counts (1 .. 49), targets, rules and cuts of a window into ring-carried launches (lengths
+    from 1 step up, start steps anywhere in a 16-step block): the matrix-core kernel and the VALU kernel leave identical
+    chains and acceptance counts, and their summed lag products / the window's head and tail sums agree to FP32 rounding."""
+    from mcmc_amd import lib as L
+    rng = np.random.default_rng(20251111)
+    targets = [(O.R2WS, 2.0, 0.54), (O.WS, 3.0, 0.5), (O.GAUSS, 1.5, 0.0), (O.R2GAUSS, 0.8, 0.0)]
+    rules = [(L.ACCEPT_CROSS, L.MATH_FAST), (L.ACCEPT_RECIP, L.MATH_FAST), (L.ACCEPT_LOG, L.MATH_FAST), (L.ACCEPT_NODIV, L.MATH_FAST),
+             (L.ACCEPT_RECIP, L.MATH_PRECISE)]
+    for case in range(12):
+        n_chains = int(rng.choice([1, 63, 64, 65, 200, 257, 777]))
+        n_lags = int(rng.choice([1, 2, 7, 16, 33, 49]))
+        target = targets[case % 4]
+        rule, math = rules[case % 5]
+        first = n_lags + int(rng.integers(0, 70))          # a window's first launch holds at least n_lags steps
+        cuts = [first] + [int(x) for x in rng.choice([1, 2, 5, 15, 16, 17, 48, 49, 50, 130], size=int(rng.integers(1, 5)))]
+        t0 = int(rng.integers(0, 1000))
+        res = {}
+        for opt in (b"1", b"0"):
+            lag_option(opt)
+            eng = _engine(dev, n_chains=n_chains, n_coords=2, target=target, step=1.7, precision=32, accept_rule=rule,
+                          math_mode=math, n_lags=n_lags, center=1.0, seed=1000 + case, carry_ring=True)
+            eng.steps_done = t0
+            tot = None
+            for i, m in enumerate(cuts):
+                last = eng.run(m, window_start=(i == 0)).cpu().numpy().copy()
+                if tot is None:
+                    tot = last.copy()
+                else:
+                    tot[:, :3 + n_lags] += last[:, :3 + n_lags]
+                tot[:, 3 + 2 * n_lags:] = last[:, 3 + 2 * n_lags:]
+            torch.cuda.synchronize()
+            res[opt] = (tot, eng.state.cpu().numpy().copy(), eng.ring.cpu().numpy().copy())
+        (a, sa, ra), (b, sb, rb) = res[b"1"], res[b"0"]
+        tag = (case, n_chains, n_lags, cuts, t0)
+        assert np.array_equal(sa, sb), tag
+        assert np.array_equal(ra, rb), tag
+        np.testing.assert_array_equal(a[:, 2], b[:, 2], err_msg=str(tag))
+        n = n_chains * sum(cuts)
+        scale = max(float(np.abs(b[:, 1]).max()), 1.0)      # sum y^2 bounds every sum |y_t y_{t-k}|
+        np.testing.assert_allclose(a[:, :2], b[:, :2], rtol=2e-6, atol=1e-4 * n, err_msg=str(tag))
+        np.testing.assert_allclose(a[:, 3:3 + n_lags], b[:, 3:3 + n_lags], rtol=0, atol=4e-6 * scale + 1e-6 * n, err_msg=str(tag))
+        np.testing.assert_allclose(a[:, 3 + n_lags:], b[:, 3 + n_lags:], rtol=2e-6, atol=2e-5 * n_chains + 1e-4, err_msg=str(tag))
