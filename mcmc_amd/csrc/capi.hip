@@ -265,6 +265,7 @@ int mcmc::create_handle(const mcmc_config *cfg, uint64_t events, mcmc_handle *ou
         return set_error(MCMC_EINVAL, "negative nucleon count");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_error(MCMC_ENODEV, "no HIP device");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(cfg->device));
     mcmc_handle h = new mcmc_handle_s();
     std::memset(h, 0, sizeof(*h));
@@ -322,6 +323,7 @@ int mcmc::create_handle(const mcmc_config *cfg, uint64_t events, mcmc_handle *ou
 extern "C" int mcmc_destroy(mcmc_handle h)
 {
     if (!h) return set_error(MCMC_EINVAL, "null handle");
+    DeviceGuard restore_device;
     (void)hipSetDevice(h->cfg.device);
     free_handle(h);
     return MCMC_OK;
@@ -338,6 +340,7 @@ extern "C" int mcmc_warmup(mcmc_handle h, float stepsize, int iterations)
 {
     if (!h) return set_error(MCMC_EINVAL, "null handle");
     if (iterations < 0) return set_error(MCMC_EINVAL, "iterations must be >= 0");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     mcmc_xs_args a = xs_args(h, stepsize);
     int rc = mcmc_launch_warmup_metropolis(&a, (uint32_t)iterations, h->stream);
@@ -350,6 +353,7 @@ extern "C" int mcmc_warmup(mcmc_handle h, float stepsize, int iterations)
 extern "C" int mcmc_init_from_pdf(mcmc_handle h)
 {
     if (!h) return set_error(MCMC_EINVAL, "null handle");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     mcmc_xs_args a = xs_args(h, h->cfg.stepsize);
     return mcmc_launch_init_sample_from_pdf(&a, h->stream);
@@ -359,6 +363,7 @@ extern "C" int mcmc_integrate_r2(mcmc_handle h, float stepsize, int samples, flo
 {
     if (!h || !out_run_mean) return set_error(MCMC_EINVAL, "null pointer");
     if (samples <= 0) return set_error(MCMC_EINVAL, "samples must be > 0");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     mcmc_xs_args a = xs_args(h, stepsize);
     int rc = mcmc_launch_integrate_r2(&a, h->d_result, (uint32_t)samples, h->d_means, h->stream);
@@ -376,6 +381,7 @@ extern "C" int mcmc_integrate_sab(mcmc_handle h, float stepsize, int samples, fl
 {
     if (!h || !out_run_mean) return set_error(MCMC_EINVAL, "null pointer");
     if (samples <= 0) return set_error(MCMC_EINVAL, "samples must be > 0");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     mcmc_xs_args a = xs_args(h, stepsize);
     int rc = mcmc_launch_integrate_sab(&a, h->d_result, (uint32_t)samples, b, h->d_means, hits4 ? h->d_means + 1 : nullptr,
@@ -399,6 +405,7 @@ extern "C" int mcmc_run_rms(mcmc_handle h, float *rms, float *rms_stderr)
     const int R = h->cfg.totalRuns;
     if (R <= 0) return set_error(MCMC_EINVAL, "totalRuns must be > 0");
     if (h->cfg.samplesPerThread <= 0) return set_error(MCMC_EINVAL, "samplesPerThread must be > 0");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     int rc = ensure_scan_buffer(h, (size_t)R * h->nN);
     if (rc) return rc;
@@ -432,6 +439,7 @@ extern "C" int mcmc_run_sab_scan(mcmc_handle h, float *b_out, float *S_AB, float
     if (R <= 0) return set_error(MCMC_EINVAL, "totalRuns must be > 0");
     if (nb <= 0) return set_error(MCMC_EINVAL, "ndbs must be > 0");
     if (h->cfg.samplesPerThread <= 0) return set_error(MCMC_EINVAL, "samplesPerThread must be > 0");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     int rc = ensure_scan_buffer(h, (size_t)nb * R * 5);
     if (rc) return rc;
@@ -475,6 +483,7 @@ extern "C" int mcmc_run_inel_scan(mcmc_handle h, float *b_out, double *p_inel, d
     if (R <= 0) return set_error(MCMC_EINVAL, "totalRuns must be > 0");
     if (nb <= 0) return set_error(MCMC_EINVAL, "ndbs must be > 0");
     if (h->cfg.samplesPerThread <= 0) return set_error(MCMC_EINVAL, "samplesPerThread must be > 0");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     int rc = ensure_scan_buffer(h, (size_t)nb * R * 2);
     if (rc) return rc;
@@ -538,6 +547,7 @@ extern "C" int mcmc_run_all(mcmc_handle h, double *sigma6)
 extern "C" int mcmc_get_state(mcmc_handle h, float *host_out)
 {
     if (!h || !host_out) return set_error(MCMC_EINVAL, "null pointer");
+    DeviceGuard restore_device;
     MCMC_HIP_CHECK(hipSetDevice(h->cfg.device));
     MCMC_HIP_CHECK(hipStreamSynchronize(h->stream));
     MCMC_HIP_CHECK(hipMemcpy(host_out, h->d_prev, sizeof(float) * h->nN * h->T, hipMemcpyDeviceToHost));

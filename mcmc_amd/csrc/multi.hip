@@ -236,6 +236,7 @@ int check_multi_scan(mcmc_multi m)
 extern "C" int mcmc_multi_create(const mcmc_config *cfg, const int *devices, int n_shards, int reduce, mcmc_multi *out)
 {
     if (!cfg || !out) return set_error(MCMC_EINVAL, "null pointer");
+    DeviceGuard restore_device;
     int rc = check_devices(devices, n_shards);
     if (rc) return rc;
     if (cfg->totalBlocks <= 0 || cfg->threadsPerBlock <= 0) return set_error(MCMC_EINVAL, "totalBlocks and threadsPerBlock must be > 0");
@@ -289,6 +290,7 @@ extern "C" int mcmc_multi_create(const mcmc_config *cfg, const int *devices, int
 extern "C" int mcmc_multi_destroy(mcmc_multi m)
 {
     if (!m) return set_error(MCMC_EINVAL, "null handle");
+    DeviceGuard restore_device;
     for (auto &s : m->shards) {
         (void)hipSetDevice(s.device);
         if (s.h) (void)hipStreamSynchronize(s.h->stream);
@@ -325,12 +327,14 @@ extern "C" mcmc_handle mcmc_multi_shard(mcmc_multi m, int shard)
 extern "C" int mcmc_multi_warmup(mcmc_multi m, float stepsize, int iterations) // main.cu:149-152 on every shard
 {
     if (!m) return set_error(MCMC_EINVAL, "null handle");
+    DeviceGuard restore_device;
     return for_each_shard(m->W, [&](int r) { return mcmc_warmup(m->shards[r].h, stepsize, iterations); });
 }
 
 extern "C" int mcmc_multi_init_from_pdf(mcmc_multi m)
 {
     if (!m) return set_error(MCMC_EINVAL, "null handle");
+    DeviceGuard restore_device;
     return for_each_shard(m->W, [&](int r) { return mcmc_init_from_pdf(m->shards[r].h); });
 }
 
@@ -342,6 +346,7 @@ extern "C" int mcmc_multi_run_rms(mcmc_multi m, float *rms, float *rms_stderr)
     int rc = check_multi_scan(m);
     if (rc) return rc;
     if (!rms || !rms_stderr) return set_error(MCMC_EINVAL, "null pointer");
+    DeviceGuard restore_device;
     const int R = m->cfg.totalRuns, nN = m->nN;
     const size_t len = (size_t)R * nN * 4;
     rc = for_each_shard(m->W, [&](int r) {
@@ -385,6 +390,7 @@ extern "C" int mcmc_multi_run_sab_scan(mcmc_multi m, float *b_out, float *S_AB, 
     int rc = check_multi_scan(m);
     if (rc) return rc;
     if (!b_out || !S_AB || !S_AB_stderr) return set_error(MCMC_EINVAL, "null pointer");
+    DeviceGuard restore_device;
     const int R = m->cfg.totalRuns, nb = m->cfg.ndbs;
     if (nb <= 0) return set_error(MCMC_EINVAL, "ndbs must be > 0");
     const size_t len = (size_t)nb * R * 8;
@@ -438,6 +444,7 @@ extern "C" int mcmc_multi_run_inel_scan(mcmc_multi m, float *b_out, double *p_in
     int rc = check_multi_scan(m);
     if (rc) return rc;
     if (!b_out || !p_inel) return set_error(MCMC_EINVAL, "null pointer");
+    DeviceGuard restore_device;
     const int R = m->cfg.totalRuns, nb = m->cfg.ndbs;
     if (nb <= 0) return set_error(MCMC_EINVAL, "ndbs must be > 0");
     const size_t len = (size_t)nb * R * 2;
@@ -702,6 +709,7 @@ extern "C" int mcmc_stepsize_run_multi(const mcmc_target *target, int precision,
                                        uint64_t seed, double x0, const int *devices, int n_shards, int reduce,
                                        mcmc_chain_summary *summary, double *rho, void *samples_host)
 {
+    DeviceGuard restore_device; // declared first: the job's destructor switches devices too
     StepsizeJob job;
     int rc = job.open(devices, n_shards, reduce);
     if (rc) return rc;
@@ -733,6 +741,7 @@ extern "C" int mcmc_tune_stepsize(const mcmc_target *target, double lo, double h
     if (!(lo > 0.0) || !(hi > lo) || n_widths < 3) return set_error(MCMC_EINVAL, "need 0 < lo < hi and n_widths >= 3");
     if (n_steps <= (uint64_t)MCMC_MAX_LAGS + 1) return set_error(MCMC_EINVAL, "n_steps must exceed MCMC_MAX_LAGS + 1");
     std::vector<double> w(n_widths), acc(n_widths), tau(n_widths);
+    DeviceGuard restore_device;
     int dev = 0;
     int rc = current_device(&dev);
     if (rc) return rc;

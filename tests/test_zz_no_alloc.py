@@ -1,6 +1,7 @@
 """mcmc_chain_run_noalloc (the entry point for callers that cannot allocate: HIP graph capture, serving loops)
 against mcmc_chain_run, through the C ABI: identical statistics and states, two calls in a row, the second with a
-smaller input; oversize arguments are refused.  Collected last (test_zz_*) so that a failure here hides nothing."""
+smaller input; oversize arguments are refused; a sequence of launches captured in a HIP graph and replayed equals
+the same launches issued eagerly.  Collected last (test_zz_*) so that a failure here hides nothing."""
 import ctypes as C
 
 import numpy as np
@@ -58,3 +59,29 @@ def test_noalloc_rejects_beyond_the_scratch_size(dev):
         eng.run(64, noalloc=True)
     eng.run(64)  # the workspace form still takes it
     torch.cuda.synchronize()
+
+
+def test_noalloc_launches_captured_in_a_hip_graph(dev):
+    from mcmc_amd import api, lib as L
+    kw = dict(n_coords=2, target=api.make_target(L.TARGET_R2WS, 2.0, 0.54), step=2.48, precision=32,
+              accept_rule=L.ACCEPT_CROSS, math_mode=L.MATH_FAST, n_lags=49, center=2.3, seed=7, chain_offset=99, device=dev)
+    ref, na = api.ChainEngine(5000, **kw), api.ChainEngine(5000, **kw)
+    # include/mcmc_hip.h: one chain launch on the device before the capture resolves the scratch address
+    ref.run(64)
+    na.run(64)
+    torch.cuda.synchronize()
+    before = na.state.clone()
+    side = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for i in range(3):
+            na.run(64, window_start=(i == 0), noalloc=True)
+    torch.cuda.synchronize()
+    assert torch.equal(na.state, before)          # captured, not run
+    graph.replay()
+    for i in range(3):
+        ref.run(64, window_start=(i == 0))
+    torch.cuda.synchronize()
+    assert torch.equal(ref.state, na.state)
+    assert torch.equal(ref.stats, na.stats)
+    assert float(na.stats[0, 2]) > 0
