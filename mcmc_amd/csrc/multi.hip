@@ -495,18 +495,22 @@ constexpr uint64_t STEPSIZE_SEGMENT = 65536;
 // Deterministic and the same on every shard (a warm-up mean would need an exchange of its own).
 double target_mean(const mcmc_target &t, double x0)
 {
-    if (t.kind == MCMC_TARGET_GAUSS) return 0.0;
-    if (t.kind == MCMC_TARGET_WS) return x0; // 1 / (1 + e^((r-c)/a)) does not decay for r -> -inf: no mean
+    // every density of Distributions.cuh:7-28 / metropolis.hpp:9-17 is 0 for r < 0: the integrals run over [0, hi]
     const int n = 8192;
     double hi, s0 = 0, s1 = 0;
-    if (t.kind == MCMC_TARGET_R2WS) hi = (double)t.p0 + 40.0 * (double)t.p1;
+    if (t.kind == MCMC_TARGET_WS || t.kind == MCMC_TARGET_R2WS) hi = (double)t.p0 + 40.0 * (double)t.p1;
     else hi = 12.0 * std::sqrt((double)t.p0);
     if (!(hi > 0.0) || !std::isfinite(hi)) return x0;
     const double h = hi / n;
     for (int i = 0; i < n; ++i) {
         const double r = (i + 0.5) * h;
-        const double p = t.kind == MCMC_TARGET_R2WS ? r * r / (1 + std::exp((r - (double)t.p0) / (double)t.p1)) // metropolis.hpp:9-12
-                                                    : r * r * std::exp(-r * r / (2 * (double)t.p0));            // metropolis.hpp:14-17
+        double p;
+        switch (t.kind) {
+        case MCMC_TARGET_WS: p = 1 / (1 + std::exp((r - (double)t.p0) / (double)t.p1)); break;         // Distributions.cuh:7-10
+        case MCMC_TARGET_R2WS: p = r * r / (1 + std::exp((r - (double)t.p0) / (double)t.p1)); break;   // metropolis.hpp:9-12
+        case MCMC_TARGET_GAUSS: p = std::exp(-r * r / (2 * (double)t.p0)); break;                      // Distributions.cuh:19-22
+        default: p = r * r * std::exp(-r * r / (2 * (double)t.p0)); break;                             // metropolis.hpp:14-17
+        }
         s0 += p;
         s1 += p * r;
     }
