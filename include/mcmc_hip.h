@@ -350,6 +350,10 @@ typedef struct {
     const char *outDir;        /* main.cu:73 ("../data/"); NULL = "./"                                  */
     const char *outFile;       /* main.cu:74,77-79 ("out.root"; argv[1]); NULL = "out"; the library appends
                                   ".RMS.csv" / ".S_AB.csv" (TTree columns of IntegrationOutputHandler.cuh:83-112) */
+    const mcmc_target *nucleon_targets; /* NULL, or one density per NUCLEON in pdfArr order -- protons A, neutrons A,
+                                  protons B, neutrons B (MCMCMacro.py:315-345; SetNeutronPDFA(pdf, i) etc., :172-199) --
+                                  nNucleonsA + nNucleonsB entries (host memory, read by mcmc_create /
+                                  mcmc_multi_create only); overrides the four per-species densities above */
 } mcmc_config;
 
 typedef struct mcmc_handle_s *mcmc_handle;

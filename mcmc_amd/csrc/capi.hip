@@ -283,10 +283,15 @@ int mcmc::create_handle(const mcmc_config *cfg, uint64_t events, mcmc_handle *ou
     // per-nucleon densities in the order of TemplateBuilder::ConcatArray(pdfArrA, pdfArrB)
     // (main.cu:49-51; MCMCMacro.py:315-345 concatenates protons A, neutrons A, protons B, neutrons B)
     std::vector<mcmc_target> tg;
-    for (int i = 0; i < cfg->nProtonA; i++) tg.push_back(cfg->protonA);
-    for (int i = 0; i < cfg->nNeutronA; i++) tg.push_back(cfg->neutronA);
-    for (int i = 0; i < cfg->nProtonB; i++) tg.push_back(cfg->protonB);
-    for (int i = 0; i < cfg->nNeutronB; i++) tg.push_back(cfg->neutronB);
+    if (cfg->nucleon_targets) { // one density per nucleon, already in that order (MCMCMacro.py:172-199)
+        tg.assign(cfg->nucleon_targets, cfg->nucleon_targets + h->nN);
+    } else {
+        for (int i = 0; i < cfg->nProtonA; i++) tg.push_back(cfg->protonA);
+        for (int i = 0; i < cfg->nNeutronA; i++) tg.push_back(cfg->neutronA);
+        for (int i = 0; i < cfg->nProtonB; i++) tg.push_back(cfg->protonB);
+        for (int i = 0; i < cfg->nNeutronB; i++) tg.push_back(cfg->neutronB);
+    }
+    h->cfg.nucleon_targets = nullptr; // the caller's array is not kept: the densities live in d_targets
     h->uniform_kind = tg[0].kind;
     for (const auto &t : tg) {
         if (t.kind < 0 || t.kind > 3) { delete h; return set_error(MCMC_EINVAL, "bad target kind"); }

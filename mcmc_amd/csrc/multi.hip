@@ -248,6 +248,7 @@ extern "C" int mcmc_multi_create(const mcmc_config *cfg, const int *devices, int
 
     mcmc_multi m = new mcmc_multi_s();
     m->cfg = *cfg;
+    m->cfg.nucleon_targets = nullptr; // read by the shards' create_handle below (from *cfg), not kept
     m->W = n_shards;
     m->use_rccl = use_rccl;
     m->T_total = T;

@@ -12,6 +12,9 @@
 //   totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix
 //   b0 db ndbs seed stepsize sigmaNN beta outDir outFile integrateRMS integrateSAB
 //   blackDisk=1 (adds the hit-test inelastic probability, d < sqrt(sigmaNN/pi))  math=fast|precise
+//   macro=<file>  a macro file written by the reference's generator (MCMCMacro.py:285-372; main.cu:22-37 compiles one
+//   executable per macro): its constants and per-nucleon densities are read at run time (macro.hpp); arguments after
+//   it override it.  printConfig=1 prints the effective configuration and exits without touching the GPU.
 //   devices=0,1,...  reduce=auto|host|rccl : the events (totalBlocks x threadsPerBlock) partitioned over these GPUs, one
 //   host thread and stream per GPU, ONE all-reduce of the scan's sufficient statistics (mcmc_multi_*, include/mcmc_hip.h
 //   Layer C); results are bit-identical for any device list.  Without devices=: the one-GPU handle on `device`.
@@ -25,8 +28,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
+#include "macro.hpp"
 #include "mcmc_hip.h"
 #include "output.hpp"
 
@@ -77,6 +82,8 @@ int main(int argc, char **argv)
     bool autoStep = false, randomStart = false;
     std::vector<int> devices; // devices=...: the multi-GPU path
     int reduce = MCMC_REDUCE_AUTO;
+    std::vector<mcmc_target> perNucleon; // macro=...: one density per nucleon (pdfArr order), else empty
+    bool printConfig = false;
 
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -89,7 +96,7 @@ int main(int argc, char **argv)
             std::puts("usage: xsection [name=value ...]   names: nNeutronA nProtonA nNeutronB nProtonB isotopeA isotopeB pdf pdfA\n"
                       "       pdfB totalBlocks threadsPerBlock samplesPerThread totalRuns samplesForMix b0 db ndbs seed stepsize\n"
                       "       sigmaNN beta outDir outFile integrateRMS integrateSAB blackDisk inelOnly randomStart rule math device\n"
-                      "       devices=0,1,... reduce=auto|host|rccl");
+                      "       devices=0,1,... reduce=auto|host|rccl macro=<file written by MCMCMacro.py> printConfig=1");
             return a == "--help" || a == "-h" ? 0 : 2;
         }
         const std::string k = a.substr(0, eq), v = a.substr(eq + 1);
@@ -97,7 +104,52 @@ int main(int argc, char **argv)
         const float fv = (float)std::atof(v.c_str());
         mcmc_target t;
         int Z, A;
-        if (k == "nNeutronA") cfg.nNeutronA = iv;
+        // a nucleus or density given after macro= replaces the macro's per-nucleon list by the per-species densities
+        if (k == "nNeutronA" || k == "nProtonA" || k == "nNeutronB" || k == "nProtonB" || k == "isotopeA" || k == "isotopeB" ||
+            k == "pdf" || k == "pdfA" || k == "pdfB")
+            perNucleon.clear();
+        if (k == "macro") { // IntegrationSettings.GenerateCode output, read instead of compiled (main.cu:22-37)
+            mcmc_host::MacroSettings ms;
+            std::string err;
+            if (!mcmc_host::read_macro(v, ms, err)) {
+                std::fprintf(stderr, "xsection: macro %s: %s\n", v.c_str(), err.c_str());
+                return 2;
+            }
+            auto num = [&](const char *name, auto &dst) {
+                const auto it = ms.numbers.find(name);
+                if (it != ms.numbers.end()) dst = static_cast<std::decay_t<decltype(dst)>>(it->second);
+            };
+            num("nNeutronA", cfg.nNeutronA), num("nProtonA", cfg.nProtonA), num("nNeutronB", cfg.nNeutronB), num("nProtonB", cfg.nProtonB);
+            num("totalBlocks", cfg.totalBlocks), num("threadsPerBlock", cfg.threadsPerBlock), num("samplesPerThread", cfg.samplesPerThread);
+            num("totalRuns", cfg.totalRuns), num("samplesForMix", cfg.samplesForMix), num("b0", cfg.b0), num("db", cfg.db), num("ndbs", cfg.ndbs);
+            num("integrateRMS", integrateRMS), num("integrateSAB", integrateSAB);
+            if (ms.has_seed) cfg.seed = ms.seed;
+            else if (ms.seed_from_clock) std::printf("macro: seed taken from the clock there; using %llu (seed=... overrides)\n", (unsigned long long)cfg.seed);
+            if (ms.strings.count("outDir")) outDir = ms.strings["outDir"];
+            if (ms.strings.count("outFile")) { // "out.root" names the reference's ROOT file; the CSV tables take its stem
+                outFile = ms.strings["outFile"];
+                if (outFile.size() > 5 && outFile.compare(outFile.size() - 5, 5, ".root") == 0) outFile.erase(outFile.size() - 5);
+            }
+            for (const char *name : {"integrateIAB", "integrateJAB"})
+                if (ms.numbers.count(name) && ms.numbers[name] != 0.0)
+                    std::printf("macro: %s is set; the reference's main.cu has no such integral, neither has this driver\n", name);
+            for (const auto &n : ms.notes) std::printf("macro: %s\n", n.c_str());
+            if (!ms.nucleons.empty()) {
+                const size_t nA = (size_t)cfg.nProtonA + cfg.nNeutronA, nB = (size_t)cfg.nProtonB + cfg.nNeutronB;
+                if (ms.nucleons.size() != nA + nB) {
+                    std::fprintf(stderr, "xsection: macro %s: pdfArr has %zu densities for %zu + %zu nucleons\n", v.c_str(),
+                                 ms.nucleons.size(), nA, nB);
+                    return 2;
+                }
+                perNucleon = ms.nucleons;
+                // the per-species fields follow the first nucleon of each group (autoStep, printConfig)
+                if (cfg.nProtonA > 0) cfg.protonA = perNucleon[0];
+                if (cfg.nNeutronA > 0) cfg.neutronA = perNucleon[cfg.nProtonA];
+                if (cfg.nProtonB > 0) cfg.protonB = perNucleon[nA];
+                if (cfg.nNeutronB > 0) cfg.neutronB = perNucleon[nA + cfg.nProtonB];
+            }
+        } else if (k == "printConfig") printConfig = iv != 0;
+        else if (k == "nNeutronA") cfg.nNeutronA = iv;
         else if (k == "nProtonA") cfg.nProtonA = iv;
         else if (k == "nNeutronB") cfg.nNeutronB = iv;
         else if (k == "nProtonB") cfg.nProtonB = iv;
@@ -151,6 +203,32 @@ int main(int argc, char **argv)
     cfg.outFile = outFile.c_str(); // black-disk / inelastic-only / tuned-width options around the same calls)
     cfg.integrateRMS = integrateRMS;
     cfg.integrateSAB = integrateSAB;
+    cfg.nucleon_targets = perNucleon.empty() ? nullptr : perNucleon.data();
+    if (printConfig) { // the effective configuration, one name per line; densities as runs of equal neighbours in pdfArr order
+        std::printf("nNeutronA %d\nnProtonA %d\nnNeutronB %d\nnProtonB %d\n", cfg.nNeutronA, cfg.nProtonA, cfg.nNeutronB, cfg.nProtonB);
+        std::printf("totalBlocks %d\nthreadsPerBlock %d\nsamplesPerThread %d\ntotalRuns %d\nsamplesForMix %d\n", cfg.totalBlocks,
+                    cfg.threadsPerBlock, cfg.samplesPerThread, cfg.totalRuns, cfg.samplesForMix);
+        std::printf("b0 %.9g\ndb %.9g\nndbs %d\nseed %llu\nstepsize %.9g\nsigmaNN %.9g\nbeta %.9g\n", cfg.b0, cfg.db, cfg.ndbs,
+                    (unsigned long long)cfg.seed, cfg.stepsize, cfg.sigmaNN, cfg.beta);
+        std::printf("outDir %s\noutFile %s\nintegrateRMS %d\nintegrateSAB %d\n", outDir.c_str(), outFile.c_str(), (int)integrateRMS,
+                    (int)integrateSAB);
+        std::vector<mcmc_target> all(perNucleon);
+        if (all.empty()) {
+            all.insert(all.end(), (size_t)cfg.nProtonA, cfg.protonA);
+            all.insert(all.end(), (size_t)cfg.nNeutronA, cfg.neutronA);
+            all.insert(all.end(), (size_t)cfg.nProtonB, cfg.protonB);
+            all.insert(all.end(), (size_t)cfg.nNeutronB, cfg.neutronB);
+        }
+        static const char *const kinds[] = {"ws", "r2ws", "gauss", "r2gauss"};
+        for (size_t i = 0; i < all.size();) {
+            size_t j = i;
+            while (j < all.size() && all[j].kind == all[i].kind && all[j].p0 == all[i].p0 && all[j].p1 == all[i].p1) ++j;
+            std::printf("density %zu..%zu %s:%.9g:%.9g\n", i, j - 1, all[i].kind >= 0 && all[i].kind < 4 ? kinds[all[i].kind] : "?",
+                        all[i].p0, all[i].p1);
+            i = j;
+        }
+        return 0;
+    }
     if (mcmc_device_count() <= 0) {
         std::fprintf(stderr, "xsection: no HIP device (%s); this build has no CPU path\n", mcmc_last_error());
         return 3;

@@ -80,6 +80,7 @@ class Config(C.Structure):
         ("accept_rule", C.c_int32), ("math_mode", C.c_int32), ("device", C.c_int32),
         ("event_offset", C.c_uint64),
         ("integrateRMS", C.c_int32), ("integrateSAB", C.c_int32), ("outDir", C.c_char_p), ("outFile", C.c_char_p),
+        ("nucleon_targets", C.POINTER(Target)),
     ]
 
 
