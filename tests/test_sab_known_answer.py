@@ -144,3 +144,6 @@ def test_wavefront_per_event_kernel_with_pair_culling_against_the_analytic_profi
             # mean number of colliding pairs = n E_s[q(b x + s_A)] with s_A - s_j ~ N(0, 2 v I_2)
             ncoll_want = n * stats.ncx2.cdf(dmax2 / (2 * v), 2, b * b / (2 * v))
             assert h[0] / h[3] == pytest.approx(ncoll_want, rel=0.02), (b, h[0] / h[3], ncoll_want)
+            # the inelastic-flag kernel (lazy angles, probes, early exit: mcmc_launch_integrate_inel) on fresh samples
+            hi = xs.MCIntegrate_Inel(samples, b, dmax2).cpu().numpy()
+            assert hi[1] == T * samples and abs(hi[0] / hi[1] - want_inel) < 4 * err_inel, (b, hi[0] / hi[1], want_inel)
