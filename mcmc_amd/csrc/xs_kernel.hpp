@@ -363,7 +363,7 @@ __device__ __forceinline__ float hit_indicator(float d2, const HitScale &h)
 // iteration ahead) and keeps JC of its B nucleons j = lb + GB*(q0+q) in registers.  In FAST math
 // the stored positions are pre-multiplied by sqrt(log2(e)/(2 beta)), so a pair costs
 // 2 sub + mul + fma + v_exp_f32 + fma + mul.
-// CHECK (one event per wavefront, PROD): every eighth A iteration the wave tests whether the product over the pairs done
+// CHECK (one event per wavefront, PROD): every 32 A nucleons (8, 4 or 2 iterations by the number of lanes on A) the wave tests whether the product over the pairs done
 // so far has underflowed to exactly 0 -- the remaining factors are finite and cannot change it.  With hit counters the
 // loop goes on without the product (no exp); without them the sample's scan ends.  `dead` in: skip the product from the
 // start; out: the product is 0.
@@ -401,6 +401,9 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
         const float2 far = make_float2(-1.0e30f, 0.0f);
         const uint32_t KA = (nAe + GA - 1) >> p.ga_log2;
         bool alive = PROD && !(CHECK && dead); // wave-uniform
+        // the wave looks at its product after every 32 A nucleons (8 iterations of 4, 4 of 8, 2 of 16 lanes on A: the plan for
+        // Pb-Pb is GA = 16, whose 13 iterations a fixed period of 8 tested once, 128 A nucleons into the pass)
+        const uint32_t check_mask = GA >= 16u ? 1u : GA >= 8u ? 3u : 7u;
         float2 a = la < nAe ? trE[la] : far;
         for (uint32_t k = 0; k < KA; ++k) {
             const uint32_t i = la + (k << p.ga_log2);
@@ -434,7 +437,7 @@ __device__ __forceinline__ void sab_pairs(const XsParams &p, const float2 *trE, 
                 if (alive) {
                     slices(std::true_type{});
                     if constexpr (CHECK) {
-                        if ((k & 7u) == 7u && k + 1 < KA) {
+                        if ((k & check_mask) == check_mask && k + 1 < KA) {
                             float w = prod;
 #pragma unroll
                             for (int h = 0; h < H; ++h) w *= pr[h][0] * pr[h][1];
