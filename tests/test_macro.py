@@ -152,4 +152,4 @@ def test_macro_per_nucleon_densities_reach_the_device_in_order(dev, tmp_path):
         a = np.genfromtxt(tmp_path / f"one.{table}.csv", delimiter=",", names=True)
         b = np.genfromtxt(tmp_path / f"two.{table}.csv", delimiter=",", names=True)
         for col in a.dtype.names:
-            np.testing.assert_allclose(a[col], b[col], rtol=2e-6, atol=0)   # sharded sums: equal to the estimator's rounding
+            np.testing.assert_allclose(a[col], b[col], rtol=1e-5, atol=0)   # Layer B against Layer C: equal to the estimator's rounding (and one printed digit)
