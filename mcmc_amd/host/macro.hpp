@@ -128,9 +128,13 @@ struct Expr {
         double v = add();
         for (;;) {
             ws();
-            if (i + 1 < s.size() && s[i] == '<' && s[i + 1] == '<') i += 2, v = (double)((long long)v << (int)add());
-            else if (i + 1 < s.size() && s[i] == '>' && s[i + 1] == '>') i += 2, v = (double)((long long)v >> (int)add());
-            else return v;
+            const bool left = i + 1 < s.size() && s[i] == '<' && s[i + 1] == '<';
+            const bool right = i + 1 < s.size() && s[i] == '>' && s[i + 1] == '>';
+            if (!left && !right) return v;
+            i += 2;
+            const double n = add();
+            if (!(n >= 0.0 && n <= 62.0) || !(v > -9.0e18 && v < 9.0e18)) return ok = false, 0.0;
+            v = left ? (double)((long long)v << (int)n) : (double)((long long)v >> (int)n);
         }
     }
 };
@@ -239,6 +243,12 @@ inline bool read_macro(const std::string &path, MacroSettings &out, std::string 
         std::vector<std::string> quals;
         if (lp == std::string::npos || !split_decl(head.substr(0, lp), name, quals))
             return err = "cannot read the block that starts '" + trim(head) + "'", false;
+        if (name == "if" || name == "for" || name == "while" || name == "else" || name == "switch") {
+            // control flow of the hand-written block (main.cu:76-79: the lone argument as output file): not a setting
+            out.notes.push_back("skipped: " + trim(head) + " { ... }");
+            text.erase(start, rb + 1 - start);
+            continue;
+        }
         mcmc_target t{};
         std::string why;
         if (!macro_density(text.substr(lb + 1, rb - lb - 1), t, why)) return err = name + ": " + why, false;
@@ -302,7 +312,7 @@ inline bool read_macro(const std::string &path, MacroSettings &out, std::string 
                 out.seed = std::strtoull(rhs.c_str(), nullptr, 10);
             } else if (eval(rhs, out.numbers, v)) {
                 out.numbers[name] = v;
-                if (name == "seed") out.has_seed = true, out.seed = (uint64_t)v;
+                if (name == "seed" && v >= 0.0 && v < 1.8e19) out.has_seed = true, out.seed = (uint64_t)v;
             } else if (name == "seed") {
                 out.seed_from_clock = true; // std::chrono::steady_clock::now()... (MCMCMacro.py:360, main.cu:69)
             } else {

@@ -95,10 +95,15 @@ __device__ __host__ float wide(float r) { return Gaussian(r, 1.5f * 2); }
     const float db = 0.1;
     const uint64_t seed = 18446744073709551557;
     std::string outFile = "own.root";
+    if (argc == 2) {
+        outFile = argv[1];
+    }
     const bool integrateRMS = false;
+    const int ndbs = (1 << 3) + 2 * 3 - 4 / 2;
 """)
     cfg, dens, _ = print_config(f"macro={mac}")
     assert (cfg["totalBlocks"], cfg["threadsPerBlock"], cfg["integrateRMS"], cfg["outFile"]) == ("64", "128", "0", "own")
+    assert cfg["ndbs"] == "12"
     assert cfg["seed"] == "18446744073709551557"                  # all 64 bits of the seed
     assert dens == [("r2ws", np.float32(2.0), np.float32(0.54))] * 3 + [("gauss", np.float32(3.0), np.float32(0.0))] * 5
 
