@@ -17,6 +17,8 @@ import sys
 
 import numpy as np
 
+sys.dont_write_bytecode = True   # importing XSectionAnalysis.py must not leave a __pycache__ in the read-only reference tree
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import oracle_lib as O  # noqa: E402

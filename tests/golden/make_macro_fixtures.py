@@ -13,6 +13,9 @@ with the settings that produced them (macro_expected.json: what a reader of each
 import importlib.util
 import json
 import os
+import sys
+
+sys.dont_write_bytecode = True   # the reference tree is read-only by agreement: no __pycache__ next to MCMCMacro.py
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/xsection/tools/MCMCMacro.py"
