@@ -384,6 +384,35 @@ def test_inel_heavy_ion_equals_full_counters(dev, b):
         assert inel[0] < 0.5 * T * samples
 
 
+@pytest.mark.parametrize("b", [11.0, 13.5, 15.0, 16.5, 18.0, 19.5])
+def test_inel_peripheral_equals_full_counters(dev, b):
+    """Peripheral Pb-208 + Pb-208 events in the inelastic-flag kernel (probe misses, eager angles, bounding-box culling, pair
+    scan with early exit) over 16 step pairs of 512 events and two launches: the flag count equals hits[1] of the
+    full-counter kernel exactly and the chains advance identically -- from grazing (p_inel ~ 1) to b = 19.5 fm (p_inel < 1 %)."""
+    nA = nB = 208
+    T, samples = 512, 32
+    kw = dict(seed=20261112, event_offset=7)
+    xs = _xs(dev, nA, nB, T, [PB] * (nA + nB), "cross_fast", **kw)
+    full = _xs(dev, nA, nB, T, [PB] * (nA + nB), "cross_fast", **kw)
+    for eng in (xs, full):
+        eng.InitSampleFromPdf()
+        eng.WarmupMetropolis(64, stepsize=3.9)
+    dmax2 = 6.76 / np.pi
+    total = 0
+    for launch in range(2):     # the second launch starts with odd-numbered history: every event probes again first
+        inel = xs.MCIntegrate_Inel(samples - launch, b, dmax2, stepsize=3.9).clone()
+        _, _, hits = full.MCIntegrate_S_AB(samples - launch, b, stepsize=3.9, dmax2=dmax2)
+        torch.cuda.synchronize()
+        inel, hits = inel.cpu().numpy(), hits.cpu().numpy()
+        assert inel[1] == T * (samples - launch) and inel[0] == hits[1], (b, launch, inel, hits)
+        assert torch.equal(xs.prevSample, full.prevSample)
+        total += inel[0]
+    if b <= 13.5:
+        assert total > 0.5 * T * (2 * samples - 1)
+    if 15.0 <= b <= 18.0:
+        assert 0 < total < 0.9 * T * (2 * samples - 1)      # collisions happen, and not always
+
+
 def test_layer_b_inel_scan(dev):
     """mcmc_run_inel_scan == the p_inel column of mcmc_run_sab_scan on a handle with the same seed."""
     from mcmc_amd import lib as L
