@@ -335,9 +335,20 @@ class ChainWorkload:
                 "math": a.math, "lags_in_kernel": a.lags, "rng": rng_name(),
                 "parallelism": f"chains sharded over {world} GPU(s)"}
 
+    # r^2 WS(2.0, 0.54) at width 2.48: mean and variance by quadrature, acceptance from the transition operator of the chain
+    # (tests/markov_reference.py, profiles/r3_markov_operator.jsonl) -- independent of any code under test
+    KNOWN = {"mean_r": 2.3317236, "var_r": 0.9873116, "acceptance": 0.410037, "tau_int": 5.13564}
+
     def estimates(self, st, world):
-        s = self.eng.summary(stats_host=st.cpu().numpy(), n_chains=world * self.args.chains, n_steps=self.args.sweeps)
-        return {"mean_r": s[0]["mean"], "var_r": s[0]["variance"], "acceptance": s[0]["acceptance"]}
+        a = self.args
+        s = self.eng.summary(stats_host=st.cpu().numpy(), n_chains=world * a.chains, n_steps=a.sweeps)
+        out = {"mean_r": s[0]["mean"], "var_r": s[0]["variance"], "acceptance": s[0]["acceptance"]}
+        if a.step_size == 2.48 and a.rule in ("cross", "recip", "nodiv", "log"):
+            n = world * a.chains * a.sweeps            # samples of coordinate 0 in the last launch
+            se = (self.KNOWN["var_r"] * self.KNOWN["tau_int"] / n) ** 0.5
+            out["known_answers"] = dict(self.KNOWN, mean_r_deviation_in_standard_errors=(out["mean_r"] - self.KNOWN["mean_r"]) / se,
+                                        source="quadrature and transition operator (tests/markov_reference.py)")
+        return out
 
 
 class NucleonWorkload:
