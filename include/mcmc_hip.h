@@ -358,7 +358,8 @@ typedef struct {
 
 typedef struct mcmc_handle_s *mcmc_handle;
 
-void mcmc_config_default(mcmc_config *cfg);   /* the constants of main.cu:38-82 */
+void mcmc_config_default(mcmc_config *cfg);   /* the constants of main.cu:38-82; start every config from it (or from zeros):
+                                                 optional fields at the end of the struct mean "not used" only when zero */
 int mcmc_create(const mcmc_config *cfg, mcmc_handle *out);   /* cudaMalloc + RandStateInit + InitSampleArray, main.cu:123-134 */
 int mcmc_destroy(mcmc_handle h);                              /* main.cu:419-422 */
 int mcmc_warmup(mcmc_handle h, float stepsize, int iterations);   /* main.cu:149-152 */
